@@ -1,0 +1,217 @@
+#!/usr/bin/env python3
+"""bench.py -- range-block matches/s of the MI355X grey encode hot path.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg2|cfg3|cfg4|cfg5]
+
+One "step" = one pass of the hot path (pool build + range prep + sweep + finalise + codebook
+gather) over one batch of synthetic grey input that is already resident in HBM.  Default
+workload = BASELINE.json configs[1], the configuration the metric is quoted on:
+512x512 grey, 8x8 range / 16x16 domain (B=8), full search, 8 isometries -- as a batch of 64
+images per GPU so a step is milliseconds, not launch latency.  At N>1 every rank encodes its
+own batch (weak scaling: units = images, no data-path collective) and the codebooks are
+gathered to rank 0 with one RCCL gather per step (the path's only exchange).
+`--workload cfg4 --scaling strong` shards ONE 4096x4096 image's range blocks across the ranks.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant
+kernel = the pool sweep; algorithmic bytes = ranges x N_d x (n+8) per launch) and
+`cpu_baseline` (the C oracle, 1 core, bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (W, H, B, n_iso, planes per rank (weak) / total (strong), default scaling, seed key, description)
+    "cfg2": dict(W=512, H=512, B=8, n_iso=8, planes=64, scaling="weak", seed="cfg2",
+                 desc="cfg2: 512x512 synthetic grey U, 8x8 range/16x16 domain, full search (wK=125), 8 iso, batch of 64 images per GPU"),
+    "cfg2x1": dict(W=512, H=512, B=8, n_iso=8, planes=1, scaling="weak", seed="cfg2",
+                   desc="cfg2 single image: 512x512 synthetic grey U, B=8, full search, 8 iso"),
+    "cfg3": dict(W=2048, H=2048, B=4, n_iso=1, planes=1, scaling="strong", seed="cfg3",
+                 desc="cfg3: 2048x2048 synthetic grey U, 4x4 range/8x8 domain, full search (wK=1021), 1 iso"),
+    "cfg4": dict(W=4096, H=4096, B=8, n_iso=8, planes=1, scaling="strong", seed="cfg4",
+                 desc="cfg4: 4096x4096 synthetic grey U, 8x8 range/16x16 domain, full search (wK=1021), 8 iso, range blocks sharded across ranks"),
+    "cfg4iso1": dict(W=4096, H=4096, B=8, n_iso=1, planes=1, scaling="strong", seed="cfg4",
+                     desc="cfg4 parity mode: 4096x4096 synthetic grey U, B=8, full search, 1 iso (the reference algorithm)"),
+    "cfg5": dict(W=1024, H=1024, B=8, n_iso=8, planes=24, scaling="weak", seed="cfg5",
+                 desc="cfg5: 1024x1024 grey planes (RGB channels encoded independently), B=8, full search, 8 iso, 24 planes (8 RGB images) per GPU"),
+}
+
+HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+VALU_LANE_OPS = 256 * 4 * 32 * 2.4e9   # 256 CU x 4 SIMD-32 x 2.4 GHz lane-instructions/s
+
+
+def cpu_baseline(wl, img, budget_s=12.0):
+    """The oracle (C restatement of the Java loops, -O2, 1 thread) on a bounded sample of the
+    same workload: the first ranges of image 0 against its full pool."""
+    from oracle import fic_oracle as fo
+    W, H, B, n_iso = wl["W"], wl["H"], wl["B"], wl["n_iso"]
+    Rw, Rh, Dw, Dh = fo.geometry(W, H, B)
+    argb = fo.gray_to_argb(img)
+    t0 = time.perf_counter()
+    fo.encode_gray(argb, W, H, B, Dw, n_iso, 0, 2)          # includes the pool build
+    t_probe = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    fo.encode_gray(argb, W, H, B, Dw, n_iso, 0, 4)
+    t4 = time.perf_counter() - t0
+    per_range = max((t4 - t_probe) / 2.0, 1e-6)
+    n = int(max(4, min(Rw * Rh, budget_s / per_range)))
+    t0 = time.perf_counter()
+    fo.encode_gray(argb, W, H, B, Dw, n_iso, 0, n)
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "range-block matches/s", "cores": 1, "kind": "port",
+            "sample": f"first {n} of {Rw * Rh} range blocks of image 0 against the full {Dw * Dh}-block pool "
+                      f"(x{n_iso} iso), pool build included, {dt:.1f} s; C restatement of the Java loops "
+                      f"(oracle/fic_oracle.c, gcc -O2, no JVM in this image)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
+    ap.add_argument("--scaling", default=None, choices=["weak", "strong"])
+    ap.add_argument("--planes", type=int, default=None, help="override images per GPU (weak) / total (strong)")
+    ap.add_argument("--n-iso", type=int, default=None, choices=[1, 8])
+    ap.add_argument("--chunks", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=12.0)
+    args = ap.parse_args()
+
+    import torch
+    import fic_amd
+
+    wl = dict(WORKLOADS[args.workload])
+    if args.planes:
+        wl["planes"] = args.planes
+    if args.n_iso:
+        wl["n_iso"] = args.n_iso
+    scaling = args.scaling or wl["scaling"]
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one process per GPU)")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU: the hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    W, H, B, n_iso, planes = wl["W"], wl["H"], wl["B"], wl["n_iso"], wl["planes"]
+    seed = fic_amd.synth.SEEDS[wl["seed"]]
+    # synthetic input, generated once and uploaded: resident in HBM before any timing
+    if scaling == "weak":
+        imgs = np.stack([fic_amd.synth.image_u(W, H, seed + 3 * (rank * planes + p)) for p in range(planes)])
+    else:
+        imgs = np.stack([fic_amd.synth.image_u(W, H, seed + 3 * p) for p in range(planes)])
+    dev_in = torch.from_numpy(imgs).cuda()
+
+    if scaling == "strong":
+        enc = fic_amd.ShardedEncoder(W, H, B, None, n_iso, planes, local_rank)
+        core = enc.enc
+        begin, count = enc.spans[rank]
+    else:
+        core = fic_amd.Encoder(W, H, B, None, n_iso, planes, local_rank)
+        begin, count = 0, core.n_ranges
+        spans = [(0, core.n_ranges)] * world
+    core.set_gray(dev_in)
+    core.set_option("time_sweep", 1)
+    if args.chunks:
+        core.set_option("chunks", args.chunks)
+    stream = torch.cuda.current_stream()
+    res_dev = core.results_device()
+
+    def step():
+        core.encode(begin, count, stream)
+        if world > 1:
+            rec = fic_amd.pack_records(res_dev, begin, count)
+            if scaling == "strong":
+                fic_amd.gather_records(rec, enc.spans, None, 0)
+            else:
+                fic_amd.gather_records(rec, spans, None, 0)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    core.sweep_time(reset=True)
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    sweep_ms, sweep_n = core.sweep_time(reset=True)
+    if dist:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    Nr, Nd, n = core.n_ranges, core.n_domains, B * B
+    ranges_per_step_rank = count * planes
+    if scaling == "weak":
+        total_ranges = Nr * planes * world * args.steps
+    else:
+        total_ranges = Nr * planes * args.steps
+    value = total_ranges / dt
+    info = core.info()
+
+    if rank == 0:
+        avg_ms = sweep_ms / max(sweep_n, 1)
+        alg_bytes = float(ranges_per_step_rank) * Nd * (n + 8)      # n+8 bytes per (range,domain) pair
+        achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
+        pair_evals = float(ranges_per_step_rank) * Nd * n_iso
+        # VALU instructions per pair evaluation of the sweep kernel (static count from the ISA):
+        # n/4 v_dot4 + cvt + cmp per isometry copy, + 3 per (range,domain) shared by the copies
+        valu_per_eval = n / 4 + 2 + 3.0 / (n_iso if n_iso > 1 else 1)
+        valu_frac = pair_evals * valu_per_eval / (avg_ms * 1e-3) / VALU_LANE_OPS
+        out = {
+            "metric": "range-block matches/sec (8x8 R, 16x16 D, 8 iso)" if (B == 8 and n_iso == 8) else
+                      f"range-block matches/sec ({B}x{B} R, {2 * B}x{2 * B} D, {n_iso} iso)",
+            "value": value, "unit": "range-block matches/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+            "scaling": scaling, "vs_baseline": None, "dtype": "u8 dot4 -> i32 (exact), f32/f64 epilogue",
+            "data": "synthetic",
+            "config": {"workload": wl["desc"], "image": f"{W}x{H}", "B": B, "n_iso": n_iso, "wK": core.wK,
+                       "planes_per_rank" if scaling == "weak" else "planes": planes,
+                       "N_r": Nr, "N_d": Nd, "pool_chunks": info["chunks"], "parallelism": f"range/plane shards x{world}"},
+            "pair_evals_per_s": pair_evals * sweep_n / (sweep_ms * 1e-3) if sweep_ms > 0 else None,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "k_sweep_fast", "avg_launch_ms": avg_ms, "launches": sweep_n,
+                         "algorithmic_bytes_per_launch": alg_bytes,
+                         "note": "algorithmic bytes = ranges x N_d x (n+8); each wave keeps 64 range blocks in VGPRs "
+                                 "and reads a pool block once for all of them, so frac > 1 means the sweep is past the "
+                                 "HBM roofline and bounded by VALU issue instead (see valu)"},
+            "valu": {"bound": "valu-issue", "achieved_frac": valu_frac, "valu_instr_per_pair_eval": valu_per_eval,
+                     "peak_lane_ops_per_s": VALU_LANE_OPS},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(wl, imgs[0], args.cpu_budget)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

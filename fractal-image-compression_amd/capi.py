@@ -1,0 +1,107 @@
+"""ctypes binding of libfic_hip.so (include/fic.h).  Fails loudly when the library is missing:
+there is no Python or CPU fallback for the hot path."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "libfic_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "fic.h")
+
+FIC_OK = 0
+ERROR_NAMES = {
+    -1: "FIC_E_GEOMETRY", -2: "FIC_E_WINDOW", -3: "FIC_E_ARGUMENT", -4: "FIC_E_NO_DEVICE",
+    -5: "FIC_E_HIP", -6: "FIC_E_NOT_GREY", -7: "FIC_E_STATE", -8: "FIC_E_CAPACITY",
+}
+
+
+class FicError(Exception):
+    """Raised for every negative return code of the C ABI (the reference throws unchecked
+    exceptions in the same situations; CTL:184-186 catches them)."""
+
+    def __init__(self, code, message):
+        super().__init__(f"{ERROR_NAMES.get(code, code)}: {message}")
+        self.code = code
+
+
+def declared_symbols():
+    """Names of every FIC_API function declared in include/fic.h."""
+    text = open(HEADER_PATH).read()
+    return sorted(set(re.findall(r"FIC_API\s+[\w\s\*]+?\b(fic_\w+)\s*\(", text)))
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO_PATH):
+        raise FicError(-5, f"{SO_PATH} is missing: build it with __graft_entry__.build() "
+                           "(hipcc --offload-arch=gfx950); there is no fallback path")
+    L = C.CDLL(SO_PATH)
+    vp, ip = C.c_void_p, C.POINTER(C.c_int)
+    i32p, f32p, u8p = C.POINTER(C.c_int32), C.POINTER(C.c_float), C.POINTER(C.c_uint8)
+    sig = {
+        "fic_version": (C.c_char_p, []),
+        "fic_last_error": (C.c_char_p, []),
+        "fic_device_count": (C.c_int, []),
+        "fic_geometry": (C.c_int, [C.c_int, C.c_int, C.c_int, ip, ip, ip, ip]),
+        "fic_is_greyscale_argb": (C.c_int, [i32p, C.c_int, C.c_int]),
+        "fic_encode_gray_argb": (C.c_int, [i32p] + [C.c_int] * 6 + [i32p, f32p, f32p, i32p, i32p]),
+        "fic_encode_gray_u8": (C.c_int, [u8p] + [C.c_int] * 6 + [i32p, f32p, f32p, i32p, i32p]),
+        "fic_write_run_gray": (C.c_int64, [i32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, u8p, C.c_int64]),
+        "fic_ctx_create": (vp, [C.c_int] * 7),
+        "fic_ctx_destroy": (None, [vp]),
+        "fic_ctx_set_gray_host": (C.c_int, [vp, u8p]),
+        "fic_ctx_set_argb_host": (C.c_int, [vp, i32p]),
+        "fic_ctx_set_gray_device": (C.c_int, [vp, vp]),
+        "fic_ctx_encode": (C.c_int, [vp, C.c_int, C.c_int, vp]),
+        "fic_ctx_sync": (C.c_int, [vp]),
+        "fic_ctx_get_results_host": (C.c_int, [vp, i32p, f32p, f32p, i32p, i32p, i32p, f32p]),
+        "fic_ctx_result_device_ptrs": (C.c_int, [vp] + [C.POINTER(vp)] * 7),
+        "fic_ctx_collage_host": (C.c_int, [vp, i32p]),
+        "fic_ctx_set_option": (C.c_int, [vp, C.c_char_p, C.c_int]),
+        "fic_ctx_sweep_time": (C.c_int, [vp, C.POINTER(C.c_double), ip, C.c_int]),
+        "fic_ctx_info": (C.c_int, [vp, ip]),
+        "fic_debug_sqrt_f64": (C.c_int, [C.c_int, C.c_uint32, C.c_uint32, C.POINTER(C.c_double)]),
+        "fic_ctx_debug_pool_host": (C.c_int, [vp, u8p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), u8p]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = L
+    return L
+
+
+def last_error():
+    return lib().fic_last_error().decode("utf-8", "replace")
+
+
+def check(rc):
+    if rc < 0:
+        raise FicError(rc, last_error())
+    return rc
+
+
+def ptr(a, t):
+    return None if a is None else a.ctypes.data_as(C.POINTER(t))
+
+
+def geometry(w, h, B):
+    v = [C.c_int() for _ in range(4)]
+    check(lib().fic_geometry(w, h, B, *[C.byref(x) for x in v]))
+    return tuple(x.value for x in v)
+
+
+def write_run_gray(qrows, w, h, B, wK):
+    """writeData grey branch (FC:230-246): header + rows, big-endian."""
+    q = np.ascontiguousarray(qrows, np.int32).reshape(-1, 3)
+    out = np.zeros(20 + 12 * q.shape[0], np.uint8)
+    n = lib().fic_write_run_gray(ptr(q, C.c_int32), q.shape[0], w, h, B, wK, ptr(out, C.c_uint8), out.size)
+    check(int(n))
+    return out.tobytes()

@@ -1,0 +1,529 @@
+// fic_capi.cpp -- C ABI (include/fic.h) over the gfx950 kernels.  Host-side orchestration only:
+// validation, device buffers, launch order, result copies.  No compute happens on the CPU and
+// there is no CPU fallback: without a HIP device every compute entry returns FIC_E_NO_DEVICE.
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/fic.h"
+#include "fic_device.h"
+#include "fic_launch.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess) return fail(FIC_E_HIP, "%s: %s", #expr, hipGetErrorString(e_));      \
+    } while (0)
+
+int ilog2(int v)
+{
+    int l = 0;
+    while ((1 << l) < v) l++;
+    return l;
+}
+
+// Geometry as the reference derives it (FC:111-116, FC:1019-1022) + what it needs to not throw.
+int make_geometry(int w, int h, int B, int wK, int n_iso, int planes, FicGeom* out)
+{
+    if (B != 4 && B != 8 && B != 16)
+        return fail(FIC_E_GEOMETRY, "blockgroesse B=%d unsupported (GUI values 4, 8, 16; B=2 divides by zero at FC:1022)", B);
+    if (w <= 0 || h <= 0 || (w % 2) || (h % 2))
+        return fail(FIC_E_GEOMETRY, "image %dx%d: width and height must be positive and even (scaleImage FC:970-1007 overruns otherwise)", w, h);
+    if ((w % B) || (h % B))
+        return fail(FIC_E_GEOMETRY, "image %dx%d is not a multiple of B=%d (ArrayIndexOutOfBounds in the reference)", w, h, B);
+    FicGeom g;
+    memset(&g, 0, sizeof(g));
+    g.W = w; g.H = h; g.B = B; g.n = B * B; g.lgn = ilog2(B * B);
+    g.Ws = w / 2; g.Hs = h / 2; g.abstand = B / 4;
+    g.Rw = w / B; g.Rh = h / B; g.Nr = g.Rw * g.Rh;
+    g.Dw = g.Rw * 2 - 3; g.Dh = g.Rh * 2 - 3;
+    if (g.Dw < 1 || g.Dh < 1)
+        return fail(FIC_E_GEOMETRY, "image %dx%d with B=%d has no domain blocks (Dw=%d Dh=%d)", w, h, B, g.Dw, g.Dh);
+    g.Nd = g.Dw * g.Dh;
+    if ((long long)g.Nd * 8 >= 0x7FFFFFFFll || (long long)w * h >= 0x7FFFFFFFll)
+        return fail(FIC_E_GEOMETRY, "image %dx%d too large for 32-bit candidate indices", w, h);
+    if (out == nullptr) return FIC_OK;
+    if (wK < 1 || wK > g.Dw || wK > g.Dh)
+        return fail(FIC_E_WINDOW, "widthKernel wK=%d outside 1..min(Dw=%d,Dh=%d) (negative index at FC:145)", wK, g.Dw, g.Dh);
+    if (n_iso != 1 && n_iso != 8) return fail(FIC_E_ARGUMENT, "n_iso=%d: only 1 (reference) or 8 (extension)", n_iso);
+    if (planes < 1) return fail(FIC_E_ARGUMENT, "planes=%d", planes);
+    g.wK = wK; g.n_iso = n_iso; g.planes = planes;
+    g.DW = g.n / 4;
+    int NR = 1, NC = 1;
+    fic_fast_variant(B, n_iso, &NR, &NC);
+    g.NR = NR;
+    int tsz = 64 * NR;
+    g.tiles = (g.Nr + tsz - 1) / tsz;
+    g.Nr_pad = g.tiles * tsz;
+    g.Nd_pad = g.Nd + FIC_POOL_PAD;
+    g.full = (wK == g.Dw && wK == g.Dh) ? 1 : 0;
+    *out = g;
+    return FIC_OK;
+}
+
+}  // namespace
+
+struct fic_ctx {
+    int device = 0;
+    FicGeom g;
+    FicBuffers b;
+    FicOutputs o;
+    uint8_t* gray_own = nullptr;     // context-owned input copy
+    int32_t* argb_stage = nullptr;   // staging for ARGB uploads
+    int32_t* collage = nullptr;
+    bool have_input = false;
+    bool encoded_any = false;
+    hipStream_t last_stream = nullptr;
+    int opt_sweep = 0, opt_chunks = 0, opt_time = 0;
+    int last_chunks = 0, last_kind = 0;
+    std::vector<hipEvent_t> ev;      // pairs start/stop
+    double acc_ms = 0.0;
+    int acc_n = 0;
+    std::mutex mu;
+};
+
+namespace {
+
+template <typename T>
+int dev_alloc(T** p, size_t count)
+{
+    HIP_TRY(hipMalloc((void**)p, count * sizeof(T)));
+    return FIC_OK;
+}
+
+int ctx_free_all(fic_ctx* c)
+{
+    hipSetDevice(c->device);
+    for (hipEvent_t e : c->ev) hipEventDestroy(e);
+    c->ev.clear();
+    void* ptrs[] = {c->gray_own, c->argb_stage, c->collage, c->b.scaled, c->b.pool_pix, c->b.pool_st, c->b.pool_var,
+                    c->b.pool_s64, c->b.rng_pix, c->b.rng_st, c->b.key, c->o.idx_local, c->o.idx_global, c->o.iso,
+                    c->o.a, c->o.b, c->o.err, c->o.qrows};
+    for (void* p : ptrs)
+        if (p) hipFree(p);
+    return FIC_OK;
+}
+
+int flush_events(fic_ctx* c)
+{
+    for (size_t i = 0; i + 1 < c->ev.size(); i += 2) {
+        HIP_TRY(hipEventSynchronize(c->ev[i + 1]));
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, c->ev[i], c->ev[i + 1]));
+        c->acc_ms += ms;
+        c->acc_n += 1;
+        hipEventDestroy(c->ev[i]);
+        hipEventDestroy(c->ev[i + 1]);
+    }
+    c->ev.clear();
+    return FIC_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* fic_version(void) { return "fic-hip 0.1 (gfx950)"; }
+const char* fic_last_error(void) { return g_err.c_str(); }
+
+int fic_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int fic_geometry(int w, int h, int B, int* Rw, int* Rh, int* Dw, int* Dh)
+{
+    FicGeom g;
+    int rc = make_geometry(w, h, B, 1, 1, 1, &g);
+    if (rc) return rc;
+    if (Rw) *Rw = g.Rw;
+    if (Rh) *Rh = g.Rh;
+    if (Dw) *Dw = g.Dw;
+    if (Dh) *Dh = g.Dh;
+    return FIC_OK;
+}
+
+int fic_is_greyscale_argb(const int32_t* argb, int w, int h)
+{
+    if (!argb || w <= 0 || h <= 0) return fail(FIC_E_ARGUMENT, "fic_is_greyscale_argb: bad argument");
+    size_t n = (size_t)w * h;
+    for (size_t i = 0; i < n; i++) {
+        int r = (argb[i] >> 16) & 0xff, g = (argb[i] >> 8) & 0xff, b = argb[i] & 0xff;
+        if (r != g || g != b) return 0;
+    }
+    return 1;
+}
+
+int64_t fic_write_run_gray(const int32_t* qrows, int n_ranges, int w, int h, int B, int wK, uint8_t* out,
+                           int64_t capacity)
+{
+    if (!qrows || !out || n_ranges < 0) return fail(FIC_E_ARGUMENT, "fic_write_run_gray: bad argument");
+    int64_t need = 20 + 12 * (int64_t)n_ranges;
+    if (capacity < need) return fail(FIC_E_CAPACITY, "fic_write_run_gray: need %lld bytes, have %lld", (long long)need, (long long)capacity);
+    auto put = [](uint8_t* p, int32_t v) {
+        uint32_t u = (uint32_t)v;
+        p[0] = (uint8_t)(u >> 24); p[1] = (uint8_t)(u >> 16); p[2] = (uint8_t)(u >> 8); p[3] = (uint8_t)u;
+    };
+    const int32_t hdr[5] = {0, w, h, B, wK};          // FC:234-238
+    for (int i = 0; i < 5; i++) put(out + 4 * i, hdr[i]);
+    uint8_t* p = out + 20;
+    for (int64_t i = 0; i < 3 * (int64_t)n_ranges; i++, p += 4) put(p, qrows[i]);   // FC:241-245
+    return need;
+}
+
+fic_ctx* fic_ctx_create(int device, int w, int h, int B, int wK, int n_iso, int planes)
+{
+    FicGeom g;
+    if (make_geometry(w, h, B, wK, n_iso, planes, &g)) return nullptr;
+    int ndev = fic_device_count();
+    if (ndev <= 0) { fail(FIC_E_NO_DEVICE, "no HIP device visible (this library has no CPU path)"); return nullptr; }
+    if (device < 0 || device >= ndev) { fail(FIC_E_NO_DEVICE, "device %d out of range (0..%d)", device, ndev - 1); return nullptr; }
+    if (hipSetDevice(device) != hipSuccess) { fail(FIC_E_HIP, "hipSetDevice(%d) failed", device); return nullptr; }
+    fic_ctx* c = new fic_ctx();
+    c->device = device;
+    c->g = g;
+    memset(&c->b, 0, sizeof(c->b));
+    memset(&c->o, 0, sizeof(c->o));
+    const size_t P = (size_t)planes;
+    int rc = FIC_OK;
+    auto A = [&](int r) { if (rc == FIC_OK) rc = r; };
+    A(dev_alloc(&c->b.scaled, P * g.Ws * g.Hs));
+    A(dev_alloc(&c->b.pool_pix, P * g.Nd_pad * g.n));
+    A(dev_alloc(&c->b.pool_st, P * g.Nd_pad));
+    A(dev_alloc(&c->b.pool_var, P * g.Nd_pad));
+    A(dev_alloc(&c->b.pool_s64, P * g.Nd_pad));
+    A(dev_alloc(&c->b.rng_pix, P * g.Nr_pad * g.n_iso * g.DW));
+    A(dev_alloc(&c->b.rng_st, P * g.Nr_pad));
+    A(dev_alloc(&c->b.key, P * g.Nr_pad));
+    A(dev_alloc(&c->o.idx_local, P * g.Nr));
+    A(dev_alloc(&c->o.idx_global, P * g.Nr));
+    A(dev_alloc(&c->o.iso, P * g.Nr));
+    A(dev_alloc(&c->o.a, P * g.Nr));
+    A(dev_alloc(&c->o.b, P * g.Nr));
+    A(dev_alloc(&c->o.err, P * g.Nr));
+    A(dev_alloc(&c->o.qrows, P * g.Nr * 3));
+    if (rc == FIC_OK) {
+        // zero the pool once: the FIC_POOL_PAD tail blocks stay zero forever (prefetch over-read)
+        hipError_t e = hipMemset(c->b.pool_pix, 0, P * g.Nd_pad * g.n);
+        if (e == hipSuccess) e = hipMemset(c->b.pool_st, 0, P * g.Nd_pad * sizeof(FicDomStat));
+        if (e == hipSuccess) e = hipMemset(c->b.pool_var, 0, P * g.Nd_pad * sizeof(uint32_t));
+        if (e == hipSuccess) e = hipMemset(c->b.pool_s64, 0, P * g.Nd_pad * sizeof(double));
+        if (e != hipSuccess) rc = fail(FIC_E_HIP, "hipMemset: %s", hipGetErrorString(e));
+    }
+    if (rc != FIC_OK) {
+        ctx_free_all(c);
+        delete c;
+        return nullptr;
+    }
+    return c;
+}
+
+void fic_ctx_destroy(fic_ctx* c)
+{
+    if (!c) return;
+    hipSetDevice(c->device);
+    hipDeviceSynchronize();
+    ctx_free_all(c);
+    delete c;
+}
+
+int fic_ctx_set_gray_host(fic_ctx* c, const uint8_t* gray)
+{
+    if (!c || !gray) return fail(FIC_E_ARGUMENT, "fic_ctx_set_gray_host: null argument");
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIP_TRY(hipSetDevice(c->device));
+    size_t bytes = (size_t)c->g.planes * c->g.W * c->g.H;
+    if (!c->gray_own) { int rc = dev_alloc(&c->gray_own, bytes); if (rc) return rc; }
+    HIP_TRY(hipMemcpy(c->gray_own, gray, bytes, hipMemcpyHostToDevice));
+    c->b.gray = c->gray_own;
+    c->have_input = true;
+    return FIC_OK;
+}
+
+int fic_ctx_set_argb_host(fic_ctx* c, const int32_t* argb)
+{
+    if (!c || !argb) return fail(FIC_E_ARGUMENT, "fic_ctx_set_argb_host: null argument");
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIP_TRY(hipSetDevice(c->device));
+    size_t npix = (size_t)c->g.planes * c->g.W * c->g.H;
+    if (!c->gray_own) { int rc = dev_alloc(&c->gray_own, npix); if (rc) return rc; }
+    if (!c->argb_stage) { int rc = dev_alloc(&c->argb_stage, npix); if (rc) return rc; }
+    HIP_TRY(hipMemcpy(c->argb_stage, argb, npix * sizeof(int32_t), hipMemcpyHostToDevice));
+    if (fic_launch_argb_to_gray(c->argb_stage, c->gray_own, npix, nullptr)) return fail(FIC_E_HIP, "k_argb_to_gray launch failed");
+    HIP_TRY(hipStreamSynchronize(nullptr));
+    c->b.gray = c->gray_own;
+    c->have_input = true;
+    return FIC_OK;
+}
+
+int fic_ctx_set_gray_device(fic_ctx* c, const void* dev_gray)
+{
+    if (!c || !dev_gray) return fail(FIC_E_ARGUMENT, "fic_ctx_set_gray_device: null argument");
+    std::lock_guard<std::mutex> lk(c->mu);
+    c->b.gray = (uint8_t*)dev_gray;
+    c->have_input = true;
+    return FIC_OK;
+}
+
+int fic_ctx_encode(fic_ctx* c, int range_begin, int range_count, void* hip_stream)
+{
+    if (!c) return fail(FIC_E_ARGUMENT, "fic_ctx_encode: null context");
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (!c->have_input) return fail(FIC_E_STATE, "fic_ctx_encode: no input image set");
+    const FicGeom& g = c->g;
+    if (range_count < 0) range_count = g.Nr - range_begin;
+    if (range_begin < 0 || range_count < 0 || range_begin + range_count > g.Nr)
+        return fail(FIC_E_ARGUMENT, "fic_ctx_encode: range span [%d,%d) outside 0..%d", range_begin, range_begin + range_count, g.Nr);
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t s = (hipStream_t)hip_stream;
+    c->last_stream = s;
+    if (range_count == 0) return FIC_OK;
+
+    // pool build (createCodebuch FC:119) + range prep
+    if (fic_launch_scale(c->b.gray, c->b.scaled, g, s)) return fail(FIC_E_HIP, "k_scale launch failed");
+    if (fic_launch_pool(c->b.scaled, c->b.pool_pix, c->b.pool_st, c->b.pool_var, c->b.pool_s64, g, s))
+        return fail(FIC_E_HIP, "k_pool launch failed");
+    if (fic_launch_range(c->b.gray, c->b.rng_pix, c->b.rng_st, g, s)) return fail(FIC_E_HIP, "k_range launch failed");
+
+    // sweep
+    int kind = c->opt_sweep;
+    if (kind == 0) kind = g.full ? 2 : 1;
+    if (kind == 2 && !g.full) return fail(FIC_E_ARGUMENT, "fast sweep needs full search (wK == Dw == Dh)");
+    const int tsz = 64 * g.NR;
+    const int tile0 = range_begin / tsz;
+    const int tile1 = (range_begin + range_count + tsz - 1) / tsz;
+    const int ntiles = tile1 - tile0;
+    for (int p = 0; p < g.planes; p++)
+        HIP_TRY(hipMemsetAsync(c->b.key + (size_t)p * g.Nr_pad + (size_t)tile0 * tsz, 0xFF,
+                               (size_t)ntiles * tsz * sizeof(unsigned long long), s));
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (c->opt_time) {
+        HIP_TRY(hipEventCreate(&e0));
+        HIP_TRY(hipEventCreate(&e1));
+        HIP_TRY(hipEventRecord(e0, s));
+    }
+    int nchunks = 1;
+    if (kind == 1) {
+        if (fic_launch_sweep_generic(c->b, g, range_begin, range_count, s)) return fail(FIC_E_HIP, "k_sweep_generic launch failed");
+    } else {
+        int NR, NC;
+        fic_fast_variant(g.B, g.n_iso, &NR, &NC);
+        long long base_waves = (long long)ntiles * (g.n_iso / NC) * g.planes;
+        nchunks = c->opt_chunks;
+        if (nchunks <= 0) {
+            long long want = (32768 + base_waves - 1) / base_waves;
+            long long cap = g.Nd / 2048;
+            if (cap < 1) cap = 1;
+            nchunks = (int)(want < cap ? want : cap);
+            if (nchunks < 1) nchunks = 1;
+        }
+        if (nchunks > g.Nd) nchunks = g.Nd;
+        int chunk_len = (g.Nd + nchunks - 1) / nchunks;
+        chunk_len = (chunk_len + 1) & ~1;              // even: the sweep consumes blocks in pairs
+        nchunks = (g.Nd + chunk_len - 1) / chunk_len;
+        if (nchunks * (g.n_iso / NC) > 65535) return fail(FIC_E_ARGUMENT, "too many chunks (%d)", nchunks);
+        if (fic_launch_sweep_fast(c->b, g, tile0, ntiles, chunk_len, nchunks, s)) return fail(FIC_E_HIP, "k_sweep_fast launch failed");
+    }
+    if (c->opt_time) {
+        HIP_TRY(hipEventRecord(e1, s));
+        c->ev.push_back(e0);
+        c->ev.push_back(e1);
+    }
+    c->last_chunks = nchunks;
+    c->last_kind = kind;
+    if (fic_launch_finalize(c->b, c->o, g, range_begin, range_count, s)) return fail(FIC_E_HIP, "k_finalize launch failed");
+    c->encoded_any = true;
+    return FIC_OK;
+}
+
+int fic_ctx_sync(fic_ctx* c)
+{
+    if (!c) return fail(FIC_E_ARGUMENT, "fic_ctx_sync: null context");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->last_stream));
+    return FIC_OK;
+}
+
+int fic_ctx_get_results_host(fic_ctx* c, int32_t* idx_local, float* a, float* b, int32_t* iso, int32_t* qrows,
+                             int32_t* idx_global, float* err)
+{
+    if (!c) return fail(FIC_E_ARGUMENT, "fic_ctx_get_results_host: null context");
+    if (!c->encoded_any) return fail(FIC_E_STATE, "fic_ctx_get_results_host: nothing encoded yet");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->last_stream));
+    size_t n = (size_t)c->g.planes * c->g.Nr;
+    if (idx_local) HIP_TRY(hipMemcpy(idx_local, c->o.idx_local, n * 4, hipMemcpyDeviceToHost));
+    if (a) HIP_TRY(hipMemcpy(a, c->o.a, n * 4, hipMemcpyDeviceToHost));
+    if (b) HIP_TRY(hipMemcpy(b, c->o.b, n * 4, hipMemcpyDeviceToHost));
+    if (iso) HIP_TRY(hipMemcpy(iso, c->o.iso, n * 4, hipMemcpyDeviceToHost));
+    if (qrows) HIP_TRY(hipMemcpy(qrows, c->o.qrows, n * 12, hipMemcpyDeviceToHost));
+    if (idx_global) HIP_TRY(hipMemcpy(idx_global, c->o.idx_global, n * 4, hipMemcpyDeviceToHost));
+    if (err) HIP_TRY(hipMemcpy(err, c->o.err, n * 4, hipMemcpyDeviceToHost));
+    return FIC_OK;
+}
+
+int fic_ctx_result_device_ptrs(fic_ctx* c, void** idx_local, void** a, void** b, void** iso, void** qrows,
+                               void** idx_global, void** err)
+{
+    if (!c) return fail(FIC_E_ARGUMENT, "fic_ctx_result_device_ptrs: null context");
+    if (idx_local) *idx_local = c->o.idx_local;
+    if (a) *a = c->o.a;
+    if (b) *b = c->o.b;
+    if (iso) *iso = c->o.iso;
+    if (qrows) *qrows = c->o.qrows;
+    if (idx_global) *idx_global = c->o.idx_global;
+    if (err) *err = c->o.err;
+    return FIC_OK;
+}
+
+int fic_ctx_collage_host(fic_ctx* c, int32_t* argb_out)
+{
+    if (!c || !argb_out) return fail(FIC_E_ARGUMENT, "fic_ctx_collage_host: null argument");
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (!c->encoded_any) return fail(FIC_E_STATE, "fic_ctx_collage_host: nothing encoded yet");
+    HIP_TRY(hipSetDevice(c->device));
+    size_t npix = (size_t)c->g.planes * c->g.W * c->g.H;
+    if (!c->collage) { int rc = dev_alloc(&c->collage, npix); if (rc) return rc; }
+    if (fic_launch_collage(c->b, c->o, c->collage, c->g, c->last_stream)) return fail(FIC_E_HIP, "k_collage launch failed");
+    HIP_TRY(hipStreamSynchronize(c->last_stream));
+    HIP_TRY(hipMemcpy(argb_out, c->collage, npix * sizeof(int32_t), hipMemcpyDeviceToHost));
+    return FIC_OK;
+}
+
+int fic_ctx_set_option(fic_ctx* c, const char* name, int value)
+{
+    if (!c || !name) return fail(FIC_E_ARGUMENT, "fic_ctx_set_option: null argument");
+    if (!strcmp(name, "sweep")) {
+        if (value < 0 || value > 2) return fail(FIC_E_ARGUMENT, "sweep must be 0, 1 or 2");
+        c->opt_sweep = value;
+    } else if (!strcmp(name, "chunks")) {
+        if (value < 0) return fail(FIC_E_ARGUMENT, "chunks must be >= 0");
+        c->opt_chunks = value;
+    } else if (!strcmp(name, "time_sweep")) {
+        c->opt_time = value ? 1 : 0;
+    } else {
+        return fail(FIC_E_ARGUMENT, "unknown option '%s'", name);
+    }
+    return FIC_OK;
+}
+
+int fic_ctx_sweep_time(fic_ctx* c, double* total_ms, int* launches, int reset)
+{
+    if (!c) return fail(FIC_E_ARGUMENT, "fic_ctx_sweep_time: null context");
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = flush_events(c);
+    if (rc) return rc;
+    if (total_ms) *total_ms = c->acc_ms;
+    if (launches) *launches = c->acc_n;
+    if (reset) { c->acc_ms = 0.0; c->acc_n = 0; }
+    return FIC_OK;
+}
+
+int fic_ctx_info(fic_ctx* c, int* out10)
+{
+    if (!c || !out10) return fail(FIC_E_ARGUMENT, "fic_ctx_info: null argument");
+    const FicGeom& g = c->g;
+    int v[10] = {g.Rw, g.Rh, g.Nr, g.Dw, g.Dh, g.Nd, g.NR, g.tiles, c->last_chunks, c->last_kind};
+    memcpy(out10, v, sizeof(v));
+    return FIC_OK;
+}
+
+int fic_debug_sqrt_f64(int device, uint32_t first, uint32_t count, double* out)
+{
+    if (!out || count == 0) return fail(FIC_E_ARGUMENT, "fic_debug_sqrt_f64: bad argument");
+    int ndev = fic_device_count();
+    if (ndev <= 0 || device < 0 || device >= ndev) return fail(FIC_E_NO_DEVICE, "no HIP device %d", device);
+    HIP_TRY(hipSetDevice(device));
+    double* d = nullptr;
+    HIP_TRY(hipMalloc((void**)&d, (size_t)count * sizeof(double)));
+    int rc = FIC_OK;
+    if (fic_launch_sqrt_probe(d, first, count, nullptr)) rc = fail(FIC_E_HIP, "k_sqrt_probe launch failed");
+    if (rc == FIC_OK) {
+        hipError_t e = hipMemcpy(out, d, (size_t)count * sizeof(double), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = fail(FIC_E_HIP, "hipMemcpy: %s", hipGetErrorString(e));
+    }
+    hipFree(d);
+    return rc;
+}
+
+int fic_ctx_debug_pool_host(fic_ctx* c, uint8_t* pix, uint32_t* sum, uint32_t* var, uint8_t* scaled)
+{
+    if (!c) return fail(FIC_E_ARGUMENT, "fic_ctx_debug_pool_host: null context");
+    if (!c->encoded_any) return fail(FIC_E_STATE, "fic_ctx_debug_pool_host: nothing encoded yet");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->last_stream));
+    const FicGeom& g = c->g;
+    for (int p = 0; p < g.planes; p++) {
+        if (pix)
+            HIP_TRY(hipMemcpy(pix + (size_t)p * g.Nd * g.n, c->b.pool_pix + (size_t)p * g.Nd_pad * g.n, (size_t)g.Nd * g.n,
+                              hipMemcpyDeviceToHost));
+        if (var)
+            HIP_TRY(hipMemcpy(var + (size_t)p * g.Nd, c->b.pool_var + (size_t)p * g.Nd_pad, (size_t)g.Nd * 4,
+                              hipMemcpyDeviceToHost));
+        if (sum) {
+            std::vector<FicDomStat> st(g.Nd);
+            HIP_TRY(hipMemcpy(st.data(), c->b.pool_st + (size_t)p * g.Nd_pad, (size_t)g.Nd * sizeof(FicDomStat),
+                              hipMemcpyDeviceToHost));
+            for (int i = 0; i < g.Nd; i++) sum[(size_t)p * g.Nd + i] = st[i].sum;
+        }
+    }
+    if (scaled) HIP_TRY(hipMemcpy(scaled, c->b.scaled, (size_t)g.planes * g.Ws * g.Hs, hipMemcpyDeviceToHost));
+    return FIC_OK;
+}
+
+static int encode_oneshot(const uint8_t* gray, const int32_t* argb, int w, int h, int B, int wK, int n_iso, int device,
+                          int32_t* idx_local, float* a, float* b, int32_t* iso, int32_t* qrows)
+{
+    if ((!gray && !argb) || !idx_local || !a || !b) return fail(FIC_E_ARGUMENT, "fic_encode_gray: null argument");
+    fic_ctx* c = fic_ctx_create(device, w, h, B, wK, n_iso, 1);
+    if (!c) {
+        // fic_ctx_create already set the message; recover its code from the text class
+        FicGeom g;
+        int rc = make_geometry(w, h, B, wK, n_iso, 1, &g);
+        if (rc) return rc;
+        return fic_device_count() > 0 && device >= 0 && device < fic_device_count() ? FIC_E_HIP : FIC_E_NO_DEVICE;
+    }
+    int rc = gray ? fic_ctx_set_gray_host(c, gray) : fic_ctx_set_argb_host(c, argb);
+    if (rc == FIC_OK) rc = fic_ctx_encode(c, 0, -1, nullptr);
+    if (rc == FIC_OK) rc = fic_ctx_get_results_host(c, idx_local, a, b, iso, qrows, nullptr, nullptr);
+    std::string keep = g_err;
+    fic_ctx_destroy(c);
+    g_err = keep;
+    return rc;
+}
+
+int fic_encode_gray_argb(const int32_t* argb, int w, int h, int B, int wK, int n_iso, int device, int32_t* idx_local,
+                         float* a, float* b, int32_t* iso, int32_t* qrows)
+{
+    return encode_oneshot(nullptr, argb, w, h, B, wK, n_iso, device, idx_local, a, b, iso, qrows);
+}
+
+int fic_encode_gray_u8(const uint8_t* gray, int w, int h, int B, int wK, int n_iso, int device, int32_t* idx_local,
+                       float* a, float* b, int32_t* iso, int32_t* qrows)
+{
+    return encode_oneshot(gray, nullptr, w, h, B, wK, n_iso, device, idx_local, a, b, iso, qrows);
+}
+
+}  // extern "C"

@@ -1,0 +1,728 @@
+// fic_kernels.hip -- gfx950 (MI355X / CDNA4) kernels for the bvk_ss19 grey encode hot path.
+//
+// Written for wave64 / SIMD-32 CDNA4 only.  Compile with -ffp-contract=off: every
+// float expression below must round once per operation exactly like the Java
+// reference (FractalCompression.java = FC, Domainblock.java = DB).
+//
+// Pipeline (one launch each, all planes of a batch in one grid):
+//   k_argb_to_gray   RasterImage.argb -> R channel bytes          (FC:596, FC:977)
+//   k_scale          2:1 box average                              (scaleImage     FC:970-1007)
+//   k_pool           expanded domain pool + per-block sum/var     (createCodebuch FC:1015-1050, DB:23-29,92-115)
+//   k_range          range blocks, rM/rem, isometry copies        (getRangeblock FC:588-602, getMittelwert FC:67-73)
+//   k_sweep_fast     full-pool search, lane = range block         (getBestDomainblock FC:613-632 + getErrorVarianceCovariance FC:655-687)
+//   k_sweep_generic  any window, wave = range block               (same, + getDomainBlockIndex FC:516-545, generateKernel FC:84-100)
+//   k_finalize       (a,b) fit, clamp, quantise                   (FC:634-642, writeData FC:242-244)
+//   k_collage        one-step collage image                       (getBestGeneratedCollage FC:269-300)
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <math.h>
+#include "fic_device.h"
+#include "fic_launch.h"
+
+// ---------------------------------------------------------------------------------------------
+// small device helpers
+// ---------------------------------------------------------------------------------------------
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
+#define AS4 __attribute__((address_space(4)))
+
+// Java (int) cast of a float, JLS 5.1.3: NaN -> 0, saturating.
+__device__ __forceinline__ int java_f2i(float f)
+{
+    if (f != f) return 0;
+    if (f >= 2147483648.0f) return 2147483647;
+    if (f <= -2147483648.0f) return (-2147483647 - 1);
+    return (int)f;
+}
+
+// Monotone map f32 -> u32 (unsigned order == float order); -0 folded onto +0.
+__device__ __forceinline__ uint32_t f32_orderable(float f)
+{
+    uint32_t u = __float_as_uint(f + 0.0f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float f32_from_orderable(uint32_t o)
+{
+    uint32_t u = (o & 0x80000000u) ? (o & 0x7FFFFFFFu) : ~o;
+    return __uint_as_float(u);
+}
+
+// getErrorVarianceCovariance FC:674-683 given the exact integer sums.
+//   cov  = kovarianz   (exact integer, |cov| < 2^24 so the Java float accumulation is exact)
+//   rem  = varianzRange (exact integer 0..n-1)
+//   s64  = Math.sqrt((double) varianzSquare), correctly rounded; s64 == 0  <=>  variance == 0
+__device__ __forceinline__ float exact_error(int cov, int rem, double s64)
+{
+    float remf = (float)rem;
+    float r;
+    if (rem == 0 || s64 == 0.0)
+        r = 0.0f;
+    else
+        r = (float)((double)cov / ((double)remf * s64));
+    r = __fmul_rn(r, r);
+    return __fmul_rn(__fmul_rn(remf, remf), __fsub_rn(1.0f, r));
+}
+
+// Source pixel index of isometry k at output position (x,y): out[y][x] = d[sy][sx].
+// k = 0 identity, 1 rot90cw, 2 rot180, 3 rot270cw, 4 mirror L-R, 5 mirror T-B, 6 transpose, 7 anti-transpose.
+// (Extension -- the reference has no isometries; definition shared with oracle/fic_oracle.c fo_iso_source.)
+__device__ __forceinline__ int iso_source(int k, int B, int x, int y)
+{
+    int m = B - 1, sx, sy;
+    switch (k) {
+    default:
+    case 0: sx = x;     sy = y;     break;
+    case 1: sx = y;     sy = m - x; break;
+    case 2: sx = m - x; sy = m - y; break;
+    case 3: sx = m - y; sy = x;     break;
+    case 4: sx = m - x; sy = y;     break;
+    case 5: sx = x;     sy = m - y; break;
+    case 6: sx = y;     sy = x;     break;
+    case 7: sx = m - y; sy = m - x; break;
+    }
+    return sx + sy * B;
+}
+__device__ __forceinline__ int iso_inverse(int k) { return k == 1 ? 3 : (k == 3 ? 1 : k); }
+
+// getDomainBlockIndex FC:516-545
+__device__ __forceinline__ int domain_block_index(int xr, int yr, int Rw, int Rh, int Dw)
+{
+    int i = 0;
+    if (yr == 0) yr = 1;
+    if (xr == 0) xr = 1;
+    if (yr == Rh - 1) yr = yr - 1;
+    if (xr == Rw - 1) xr = xr - 1;
+    if (xr > 1) {
+        if (yr == 0) i = xr;
+        else i = (xr * 2) - 2 + (yr + yr - 1) * Dw;
+    } else if (xr == 1) {
+        if (yr == 0) i = xr;
+        else i = xr + (yr + yr - 1) * Dw;
+    }
+    return i;
+}
+// generateKernel FC:84-100
+__device__ __forceinline__ void window_origin(int i, int Dw, int Dh, int wK, int& dy, int& dx)
+{
+    dy = i / Dw - wK / 2;
+    dx = i % Dw - wK / 2;
+    if (dx < 0) dx = 0;
+    if (dy < 0) dy = 0;
+    if (dx + wK >= Dw) dx = Dw - wK;
+    if (dy + wK >= Dh) dy = Dh - wK;
+}
+// window-local candidate -> global pool index for range j (FC:128-150)
+__device__ __forceinline__ int window_to_global(const FicGeom& g, int j, int wloc)
+{
+    if (g.full) return wloc;
+    int xr = j % g.Rw, yr = j / g.Rw;
+    int i = domain_block_index(xr, yr, g.Rw, g.Rh, g.Dw);
+    int dy, dx;
+    window_origin(i, g.Dw, g.Dh, g.wK, dy, dx);
+    int ky = wloc / g.wK, kx = wloc % g.wK;
+    return dx + kx + (dy + ky) * g.Dw;
+}
+
+// Address of dword dw of isometry copy k of range j in the lane-transposed range store:
+//   rng_pix[plane][tile][rs][k][dw][lane],  j = tile*64*NR + rs*64 + lane.
+__device__ __forceinline__ size_t rng_word_index(const FicGeom& g, int j, int k, int dw)
+{
+    int tsz = 64 * g.NR;
+    int tile = j / tsz, s = j % tsz;
+    int rs = s >> 6, lane = s & 63;
+    return ((((size_t)tile * g.NR + rs) * g.n_iso + k) * g.DW + dw) * 64 + lane;
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_argb_to_gray : RasterImage.argb (int ARGB) -> R channel bytes
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_argb_to_gray(const int32_t* __restrict__ argb, uint8_t* __restrict__ gray,
+                                                      size_t npix)
+{
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < npix) gray[i] = (uint8_t)((argb[i] >> 16) & 0xff);
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_scale : scaleImage FC:970-1007 for even W,H.  One thread per scaled pixel.
+// Quirk kept: the 4th tap is 128 when x+1 >= image.HEIGHT (FC:993).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_scale(const uint8_t* __restrict__ gray, uint8_t* __restrict__ scaled, FicGeom g)
+{
+    int xs = blockIdx.x * 256 + threadIdx.x;
+    int ys = blockIdx.y;
+    int plane = blockIdx.z;
+    if (xs >= g.Ws) return;
+    const uint8_t* im = gray + (size_t)plane * g.W * g.H;
+    int x = 2 * xs, y = 2 * ys;
+    int m = im[x + (size_t)y * g.W];
+    m += im[x + 1 + (size_t)y * g.W];
+    m += im[x + (size_t)(y + 1) * g.W];
+    m += (x + 1 >= g.H) ? 128 : (int)im[x + 1 + (size_t)(y + 1) * g.W];
+    scaled[(size_t)plane * g.Ws * g.Hs + (size_t)ys * g.Ws + xs] = (uint8_t)(m / 4);
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_pool : createCodebuch FC:1015-1050 + Domainblock DB:23-29.
+// One thread per (domain block, pixel row); B threads cooperate on a block so the pool
+// rows are written as whole B-byte runs.  Block k = (c,r) sits at scaled (c*abstand, r*abstand);
+// pixel order inside a block is rx + ry*B (FC:1036).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_pool(const uint8_t* __restrict__ scaled, uint8_t* __restrict__ pool_pix,
+                                              FicDomStat* __restrict__ pool_st, uint32_t* __restrict__ pool_var,
+                                              double* __restrict__ pool_s64, FicGeom g)
+{
+    // thread t handles row (t % B) of block (t / B)
+    const int B = g.B;
+    const int per_blk = 256 / B;                   // domain blocks per workgroup
+    int local = threadIdx.x / B, ry = threadIdx.x % B;
+    int d = blockIdx.x * per_blk + local;
+    int plane = blockIdx.y;
+    __shared__ int s_sum[256];
+    __shared__ int s_sq[256];
+    int sum = 0, sq = 0;
+    bool ok = d < g.Nd;
+    uint8_t row[16];
+    if (ok) {
+        int c = d % g.Dw, r = d / g.Dw;
+        const uint8_t* src = scaled + (size_t)plane * g.Ws * g.Hs + (size_t)(r * g.abstand + ry) * g.Ws + c * g.abstand;
+        uint8_t* dst = pool_pix + ((size_t)plane * g.Nd_pad + d) * g.n + ry * B;
+#pragma unroll
+        for (int rx = 0; rx < 16; rx++)
+            if (rx < B) {
+                int v = src[rx];
+                row[rx] = (uint8_t)v;
+                sum += v;
+                sq += v * v;
+            }
+        if (B == 4) {
+            *(uint32_t*)dst = *(uint32_t*)row;
+        } else if (B == 8) {
+            *(uint2*)dst = *(uint2*)row;
+        } else {
+            *(uint4*)dst = *(uint4*)row;
+        }
+    }
+    s_sum[threadIdx.x] = sum;
+    s_sq[threadIdx.x] = sq;
+    __syncthreads();
+    if (ok && ry == 0) {
+        int S = 0, Q = 0;
+        for (int t = 0; t < B; t++) {
+            S += s_sum[threadIdx.x + t];
+            Q += s_sq[threadIdx.x + t];
+        }
+        // mittelWert = S / n (DB:97);  variance = sum (d - m)^2 = Q - 2 m S + n m^2  (exact integer < 2^24,
+        // equal to the float accumulation of DB:110-111 because every partial sum is an exact float).
+        int m = S >> g.lgn;
+        int var = Q - 2 * m * S + g.n * m * m;
+        double s64 = __dsqrt_rn((double)var);      // Math.sqrt((double) variance), FC:677,680
+        size_t o = (size_t)plane * g.Nd_pad + d;
+        FicDomStat st;
+        st.sum = (uint32_t)S;
+        st.s32 = (float)s64;
+        pool_st[o] = st;
+        pool_var[o] = (uint32_t)var;
+        pool_s64[o] = s64;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_range : getRangeblock FC:588-602 + getMittelwert FC:67-73, and the isometry copies.
+// One thread per range block.  copy_k[pos] = r[iso_source(inverse(k), pos)] so that
+//   dot(copy_k, d) == dot(r, iso_k(d)).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_range(const uint8_t* __restrict__ gray, uint32_t* __restrict__ rng_pix,
+                                               FicRngStat* __restrict__ rng_st, FicGeom g)
+{
+    int j = blockIdx.x * 256 + threadIdx.x;
+    int plane = blockIdx.y;
+    if (j >= g.Nr_pad) return;
+    uint32_t* out = rng_pix + (size_t)plane * g.Nr_pad * g.n_iso * g.DW;
+    FicRngStat st;
+    st.rM = 0;
+    st.rem = 0;
+    if (j >= g.Nr) {     // tile padding: zero pixels, never written back
+        for (int k = 0; k < g.n_iso; k++)
+            for (int dw = 0; dw < g.DW; dw++) out[rng_word_index(g, j, k, dw)] = 0;
+        rng_st[(size_t)plane * g.Nr_pad + j] = st;
+        return;
+    }
+    const int B = g.B;
+    int x0 = (j % g.Rw) * B, y0 = (j / g.Rw) * B;
+    const uint8_t* im = gray + (size_t)plane * g.W * g.H + (size_t)y0 * g.W + x0;
+    int S = 0;
+    for (int y = 0; y < B; y++)
+        for (int x = 0; x < B; x++) S += im[(size_t)y * g.W + x];
+    st.rM = S >> g.lgn;
+    st.rem = S - (st.rM << g.lgn);
+    rng_st[(size_t)plane * g.Nr_pad + j] = st;
+    for (int k = 0; k < g.n_iso; k++) {
+        int ki = iso_inverse(k);
+        for (int dw = 0; dw < g.DW; dw++) {
+            uint32_t w = 0;
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                int pos = dw * 4 + t;
+                int src = iso_source(ki, B, pos % B, pos / B);
+                uint32_t v = im[(size_t)(src / B) * g.W + (src % B)];
+                w |= v << (8 * t);
+            }
+            out[rng_word_index(g, j, k, dw)] = w;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_sweep_generic : exact evaluation of every candidate of a window, one wave per range block.
+// Lanes stride over the wK*wK*n_iso candidates (window-major, isometry-minor), keep a running
+// (error, candidate) minimum and the wave takes the lexicographic minimum with xor-shuffles:
+// identical to the strict '<' scan in ascending order of FC:619-632.
+// Serves every wK (the GUI's 2/4/8/16 windows) and is the in-GPU cross-check of k_sweep_fast.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_sweep_generic(const uint32_t* __restrict__ pool_pix,
+                                                       const FicDomStat* __restrict__ pool_st,
+                                                       const double* __restrict__ pool_s64,
+                                                       const uint32_t* __restrict__ rng_pix,
+                                                       const FicRngStat* __restrict__ rng_st,
+                                                       unsigned long long* __restrict__ key, FicGeom g, int r_begin,
+                                                       int r_count)
+{
+    int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    int jr = blockIdx.x * 4 + wave;
+    int plane = blockIdx.y;
+    if (jr >= r_count) return;
+    int j = r_begin + jr;
+    const uint32_t* pp = pool_pix + (size_t)plane * g.Nd_pad * g.DW;
+    const FicDomStat* ps = pool_st + (size_t)plane * g.Nd_pad;
+    const double* p64 = pool_s64 + (size_t)plane * g.Nd_pad;
+    const uint32_t* rp = rng_pix + (size_t)plane * g.Nr_pad * g.n_iso * g.DW;
+    FicRngStat rs = rng_st[(size_t)plane * g.Nr_pad + j];
+    int ncand = g.wK * g.wK * g.n_iso;
+    unsigned long long best = FIC_KEY_NONE;
+    for (int c = lane; c < ncand; c += 64) {
+        int wloc = c / g.n_iso, k = c % g.n_iso;
+        int gi = window_to_global(g, j, wloc);
+        FicDomStat ds = ps[gi];
+        int dM = (int)(ds.sum >> g.lgn);
+        uint32_t acc = 0;
+        for (int dw = 0; dw < g.DW; dw++)
+            acc = __builtin_amdgcn_udot4(rp[rng_word_index(g, j, k, dw)], pp[(size_t)gi * g.DW + dw], acc, false);
+        // kovarianz = sum (r-rM)(d-dM) = sum r*d - rM*sum(d) - dM*rem   (exact integers)
+        int cov = (int)acc - rs.rM * (int)ds.sum - dM * rs.rem;
+        float e = exact_error(cov, rs.rem, p64[gi]);
+        unsigned long long kk = ((unsigned long long)f32_orderable(e) << 32) | (uint32_t)c;
+        best = kk < best ? kk : best;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        unsigned long long o = __shfl_xor(best, off, 64);
+        best = o < best ? o : best;
+    }
+    if (lane == 0) key[(size_t)plane * g.Nr_pad + j] = best;
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_sweep_fast : full-pool search (wK == Dw == Dh).
+//
+// Mapping (MI355X-first, not the CPU loop nest):
+//   * lane  = range block.  Its n pixels (and, for n_iso = 8, the 8 isometry copies) stay in
+//     VGPRs for the whole sweep: NR ranges x NC copies x DW dwords per lane.
+//   * the domain pool is the wave-uniform operand: each wave streams it through the SCALAR
+//     path (s_load_dwordx16 -> SGPRs) and feeds it straight into v_dot4_u32_u8 as the SGPR
+//     source, double-buffered so the next block's load is in flight during the current dot4s.
+//     Pool bytes are read once per wave (64*NR ranges): the LDS/register reuse the roofline
+//     analysis in DESIGN.md calls T.
+//   * every lane sees candidates in ascending index order, so Java's strict '<' tie rule
+//     (FC:627) is a per-lane running minimum: no cross-lane reduction inside a chunk; chunks
+//     and isometry groups combine with one 64-bit atomicMin on (error, candidate).
+//
+// Exactness: cov is an exact integer.  The Java error (FC:677-683) is a non-increasing
+// function of |r| = |cov| / (rem * sqrt(var)), so a candidate can only win if its |cov|/sqrt(var)
+// is not below that of the best evaluated so far.  Per pair we test  |cov| <= tau * s32  in f32
+// (tau carries a 2^-18 safety margin against <= 2^-22 of accumulated rounding);
+// only candidates failing the test run the exact f64 epilogue.  tau starts as NaN so the first
+// candidate of a chunk is always evaluated; lanes with rem == 0 (error 0 for every domain,
+// FC:677) pin tau to FLT_MAX after it.
+// ---------------------------------------------------------------------------------------------
+struct SweepArgs {
+    const uint32_t* pool_pix;
+    const FicDomStat* pool_st;
+    const double* pool_s64;
+    const uint32_t* rng_pix;
+    const FicRngStat* rng_st;
+    unsigned long long* key;
+    int Nd, Nd_pad, Nr, Nr_pad, n_iso, lgn;
+    int tile0, ntiles;         // tiles [tile0, tile0+ntiles) of 64*NR ranges
+    int chunk_len, nchunks;    // domain chunk length (multiple of 2), number of chunks
+};
+
+template <int DW, int NR, int NC>
+__global__ __launch_bounds__(256) void k_sweep_fast(SweepArgs A)
+{
+    constexpr int SEG = DW < 16 ? DW : 16;     // dwords per scalar load
+    constexpr int NSEG = DW / SEG;             // scalar loads per domain block (1, or 4 for B = 16)
+    typedef uint32_t segv __attribute__((ext_vector_type(SEG)));
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int tl = blockIdx.x * 4 + wave;
+    if (tl >= A.ntiles) return;                        // wave-uniform
+    const int tile = A.tile0 + tl;
+    const int ngroups = A.n_iso / NC;
+    const int chunk = blockIdx.y / ngroups;
+    const int kbase = (blockIdx.y % ngroups) * NC;
+    const int plane = blockIdx.z;
+
+    const int d0 = chunk * A.chunk_len;
+    int d1 = d0 + A.chunk_len;
+    if (d1 > A.Nd) d1 = A.Nd;
+    if (d0 >= d1) return;
+
+    // ---- this lane's range blocks -> VGPRs ------------------------------------------------
+    uint32_t r[NR][NC][DW];
+    int neg_rM[NR], neg_rem[NR];
+    float best_err[NR], tau[NR];
+    uint32_t best_cand[NR];
+    {
+        const uint32_t* rp = A.rng_pix + (size_t)plane * A.Nr_pad * A.n_iso * DW;
+#pragma unroll
+        for (int rs = 0; rs < NR; rs++) {
+#pragma unroll
+            for (int k = 0; k < NC; k++)
+#pragma unroll
+                for (int dw = 0; dw < DW; dw++)
+                    r[rs][k][dw] = rp[((((size_t)tile * NR + rs) * A.n_iso + kbase + k) * DW + dw) * 64 + lane];
+            FicRngStat st = A.rng_st[(size_t)plane * A.Nr_pad + ((size_t)tile * NR + rs) * 64 + lane];
+            neg_rM[rs] = -st.rM;
+            neg_rem[rs] = -st.rem;
+            best_err[rs] = INFINITY;
+            best_cand[rs] = 0xFFFFFFFFu;
+            tau[rs] = __uint_as_float(0x7FC00000u);     // NaN: first candidate always evaluated
+        }
+    }
+
+    // ---- scalar streams ---------------------------------------------------------------------
+    const AS4 segv* px = (const AS4 segv*)(A.pool_pix + (size_t)plane * A.Nd_pad * DW);
+    const AS4 u32x2* st = (const AS4 u32x2*)(A.pool_st + (size_t)plane * A.Nd_pad);
+    const AS4 double* s64p = (const AS4 double*)(A.pool_s64 + (size_t)plane * A.Nd_pad);
+
+    uint32_t acc[NR][NC];
+
+    // dot4 over one SEG-dword segment of a domain block against all resident range copies
+    auto dots = [&](const segv& p, int seg) {
+#pragma unroll
+        for (int w = 0; w < SEG; w++)
+#pragma unroll
+            for (int rs = 0; rs < NR; rs++)
+#pragma unroll
+                for (int k = 0; k < NC; k++)
+                    acc[rs][k] = __builtin_amdgcn_udot4(r[rs][k][seg * SEG + w], p[w], acc[rs][k], false);
+    };
+    auto begin_domain = [&](const u32x2& s) {
+        int Sd = (int)s.x;
+        int dM = (int)(s.x >> A.lgn);
+#pragma unroll
+        for (int rs = 0; rs < NR; rs++) {
+            // -(rM*sum(d) + dM*rem): kovarianz = sum r*d + this   (24-bit operands, exact)
+            uint32_t base = (uint32_t)(__mul24(neg_rM[rs], Sd) + __mul24(neg_rem[rs], dM));
+#pragma unroll
+            for (int k = 0; k < NC; k++) acc[rs][k] = base;
+        }
+    };
+    auto end_domain = [&](int d, const u32x2& s) {
+        float s32 = __uint_as_float(s.y);
+        bool any = false;
+        bool flag[NR][NC];
+#pragma unroll
+        for (int rs = 0; rs < NR; rs++) {
+            float lim = __fmul_rn(tau[rs], s32);
+#pragma unroll
+            for (int k = 0; k < NC; k++) {
+                float cf = fabsf((float)(int)acc[rs][k]);
+                flag[rs][k] = !(cf <= lim);            // NaN lim -> evaluate
+                any |= flag[rs][k];
+            }
+        }
+        if (__builtin_expect(__any(any), 0)) {
+            double s64 = s64p[d];
+#pragma unroll
+            for (int rs = 0; rs < NR; rs++) {
+#pragma unroll
+                for (int k = 0; k < NC; k++) {
+                    if (flag[rs][k]) {
+                        int cov = (int)acc[rs][k];
+                        float e = exact_error(cov, -neg_rem[rs], s64);
+                        if (e < best_err[rs]) {        // strict '<', ascending candidate order (FC:627)
+                            best_err[rs] = e;
+                            best_cand[rs] = (uint32_t)d * (uint32_t)A.n_iso + (uint32_t)(kbase + k);
+                        }
+                        // Any later candidate with |cov'|/sqrt(var') <= (1-2^-18) * |cov|/sqrt(var) has
+                        // |r'| <= |r| hence error' >= error >= best: it can be skipped.
+                        float lvl = (s32 == 0.0f) ? 0.0f : __fmul_rn(__fdiv_rn(fabsf((float)cov), s32), 0.99999618530273437500f);
+                        float t = tau[rs];
+                        tau[rs] = (t != t) ? lvl : fmaxf(t, lvl);
+                    }
+                }
+                if (neg_rem[rs] == 0 && best_cand[rs] != 0xFFFFFFFFu) tau[rs] = 3.402823466e+38f;
+            }
+        }
+    };
+
+    if constexpr (NSEG == 1) {
+        // two domain blocks per trip, buffers A/B; chunk_len is even, the pool tail is zero-padded
+        segv pa = px[d0];
+        u32x2 sa = st[d0];
+        for (int d = d0; d < d1; d += 2) {
+            __builtin_amdgcn_s_waitcnt(0xC07F);        // lgkmcnt(0): buffer A landed
+            segv pb = px[d + 1];
+            u32x2 sb = st[d + 1];
+            __builtin_amdgcn_sched_barrier(0);         // keep the prefetch issue above the dot4s
+            begin_domain(sa);
+            dots(pa, 0);
+            end_domain(d, sa);
+            __builtin_amdgcn_s_waitcnt(0xC07F);        // buffer B landed
+            pa = px[d + 2];
+            sa = st[d + 2];
+            __builtin_amdgcn_sched_barrier(0);
+            if (d + 1 < d1) {
+                begin_domain(sb);
+                dots(pb, 0);
+                end_domain(d + 1, sb);
+            }
+        }
+    } else {
+        // B = 16: four 16-dword segments per domain block, buffers alternate A B A B
+        segv pa = px[(size_t)d0 * NSEG];
+        u32x2 sc = st[d0];
+        for (int d = d0; d < d1; d++) {
+            const size_t sbase = (size_t)d * NSEG;
+            u32x2 sn;
+            segv pb;
+#pragma unroll
+            for (int sgi = 0; sgi < NSEG; sgi += 2) {
+                __builtin_amdgcn_s_waitcnt(0xC07F);
+                pb = px[sbase + sgi + 1];
+                __builtin_amdgcn_sched_barrier(0);
+                if (sgi == 0) begin_domain(sc);
+                dots(pa, sgi);
+                __builtin_amdgcn_s_waitcnt(0xC07F);
+                pa = px[sbase + sgi + 2];              // last trip: first segment of block d+1
+                if (sgi + 2 == NSEG) sn = st[d + 1];
+                __builtin_amdgcn_sched_barrier(0);
+                dots(pb, sgi + 1);
+            }
+            end_domain(d, sc);
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            sc = sn;
+        }
+    }
+
+    // ---- publish: lexicographic (error, candidate) minimum across chunks / isometry groups ----
+#pragma unroll
+    for (int rs = 0; rs < NR; rs++) {
+        int j = (tile * NR + rs) * 64 + lane;
+        if (j < A.Nr && best_cand[rs] != 0xFFFFFFFFu) {
+            unsigned long long kk = ((unsigned long long)f32_orderable(best_err[rs]) << 32) | best_cand[rs];
+            atomicMin(&A.key[(size_t)plane * A.Nr_pad + j], kk);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_finalize : getBestDomainblock tail FC:634-642 + writeData quantiser FC:242-244.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_finalize(const uint32_t* __restrict__ pool_pix,
+                                                  const FicDomStat* __restrict__ pool_st,
+                                                  const uint32_t* __restrict__ pool_var,
+                                                  const uint32_t* __restrict__ rng_pix,
+                                                  const FicRngStat* __restrict__ rng_st,
+                                                  const unsigned long long* __restrict__ key, FicOutputs out, FicGeom g,
+                                                  int r_begin, int r_count)
+{
+    int jr = blockIdx.x * 256 + threadIdx.x;
+    int plane = blockIdx.y;
+    if (jr >= r_count) return;
+    int j = r_begin + jr;
+    unsigned long long kk = key[(size_t)plane * g.Nr_pad + j];
+    uint32_t c = (uint32_t)kk;
+    int wloc = (int)(c / (uint32_t)g.n_iso), k = (int)(c % (uint32_t)g.n_iso);
+    int gi = window_to_global(g, j, wloc);
+    const uint32_t* pp = pool_pix + ((size_t)plane * g.Nd_pad + gi) * g.DW;
+    const uint32_t* rp = rng_pix + (size_t)plane * g.Nr_pad * g.n_iso * g.DW;
+    FicDomStat ds = pool_st[(size_t)plane * g.Nd_pad + gi];
+    FicRngStat rs = rng_st[(size_t)plane * g.Nr_pad + j];
+    uint32_t acc = 0;
+    for (int dw = 0; dw < g.DW; dw++) acc = __builtin_amdgcn_udot4(rp[rng_word_index(g, j, k, dw)], pp[dw], acc, false);
+    int dM = (int)(ds.sum >> g.lgn);
+    int cov = (int)acc - rs.rM * (int)ds.sum - dM * rs.rem;
+    float var = (float)pool_var[(size_t)plane * g.Nd_pad + gi];
+    float a = __fdiv_rn((float)cov, var);              // FC:634  (0/0 -> NaN when a flat block wins)
+    if (a < -1.0f) a = -1.0f;                          // FC:636-639 (NaN passes through)
+    else if (a > 1.0f) a = 1.0f;
+    float b = __fsub_rn((float)rs.rM, __fmul_rn(a, (float)dM));   // FC:641, never fused
+    size_t o = (size_t)plane * g.Nr + j;
+    out.qrows[3 * o + 0] = wloc;                       // (int) imageInfo[row][0]
+    out.qrows[3 * o + 1] = java_f2i(__fmul_rn(a, 100.0f));
+    out.qrows[3 * o + 2] = java_f2i(b);
+    if (a != a) a = __uint_as_float(0x7FC00000u);      // canonical NaN (Java has one NaN value)
+    if (b != b) b = __uint_as_float(0x7FC00000u);
+    out.idx_local[o] = wloc;
+    out.idx_global[o] = gi;
+    out.iso[o] = k;
+    out.a[o] = a;
+    out.b[o] = b;
+    out.err[o] = f32_from_orderable((uint32_t)(kk >> 32));
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_collage : getBestGeneratedCollage FC:269-300 -- value = clamp((int)(a*domain + b)) with the
+// UNQUANTISED float a,b (FC:287), grey ARGB out.  One thread per pixel.  For n_iso = 8 the domain
+// pixel is read through the winning isometry (extension).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_collage(const uint8_t* __restrict__ pool_pix, FicOutputs out,
+                                                 int32_t* __restrict__ collage, FicGeom g)
+{
+    int x = blockIdx.x * 256 + threadIdx.x;
+    int y = blockIdx.y;
+    int plane = blockIdx.z;
+    if (x >= g.W) return;
+    int j = (y / g.B) * g.Rw + (x / g.B);
+    int rx = x % g.B, ry = y % g.B;
+    size_t o = (size_t)plane * g.Nr + j;
+    int gi = out.idx_global[o];
+    int src = iso_source(out.iso[o], g.B, rx, ry);
+    int domain = pool_pix[((size_t)plane * g.Nd_pad + gi) * g.n + src];
+    float v = __fadd_rn(__fmul_rn(out.a[o], (float)domain), out.b[o]);
+    int value = java_f2i(v);
+    value = value < 0 ? 0 : (value > 255 ? 255 : value);
+    collage[(size_t)plane * g.W * g.H + (size_t)y * g.W + x] =
+        (int32_t)(0xff000000u | ((uint32_t)value << 16) | ((uint32_t)value << 8) | (uint32_t)value);
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_sqrt_probe : test hook -- out[i] = sqrt((double)(first + i)) as the pool kernel computes it,
+// so the test-suite can compare every possible variance value (0 .. 2^24) with the host's sqrt.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_sqrt_probe(double* __restrict__ out, uint32_t first, uint32_t count)
+{
+    uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i < count) out[i] = __dsqrt_rn((double)(first + i));
+}
+
+// =============================================================================================
+// host-side launchers
+// =============================================================================================
+#define FIC_LAUNCH_CHECK()                         \
+    do {                                           \
+        hipError_t e_ = hipGetLastError();         \
+        if (e_ != hipSuccess) return (int)e_;      \
+    } while (0)
+
+int fic_launch_argb_to_gray(const int32_t* argb, uint8_t* gray, size_t npix, hipStream_t s)
+{
+    unsigned blocks = (unsigned)((npix + 255) / 256);
+    hipLaunchKernelGGL(k_argb_to_gray, dim3(blocks), dim3(256), 0, s, argb, gray, npix);
+    FIC_LAUNCH_CHECK();
+    return 0;
+}
+
+int fic_launch_scale(const uint8_t* gray, uint8_t* scaled, const FicGeom& g, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_scale, dim3((g.Ws + 255) / 256, g.Hs, g.planes), dim3(256), 0, s, gray, scaled, g);
+    FIC_LAUNCH_CHECK();
+    return 0;
+}
+
+int fic_launch_pool(const uint8_t* scaled, uint8_t* pool_pix, FicDomStat* st, uint32_t* var, double* s64,
+                    const FicGeom& g, hipStream_t s)
+{
+    int per_blk = 256 / g.B;
+    hipLaunchKernelGGL(k_pool, dim3((g.Nd + per_blk - 1) / per_blk, g.planes), dim3(256), 0, s, scaled, pool_pix, st,
+                       var, s64, g);
+    FIC_LAUNCH_CHECK();
+    return 0;
+}
+
+int fic_launch_range(const uint8_t* gray, uint32_t* rng_pix, FicRngStat* rst, const FicGeom& g, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_range, dim3((g.Nr_pad + 255) / 256, g.planes), dim3(256), 0, s, gray, rng_pix, rst, g);
+    FIC_LAUNCH_CHECK();
+    return 0;
+}
+
+int fic_launch_sweep_generic(const FicBuffers& b, const FicGeom& g, int r_begin, int r_count, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_sweep_generic, dim3((r_count + 3) / 4, g.planes), dim3(256), 0, s,
+                       (const uint32_t*)b.pool_pix, b.pool_st, b.pool_s64, b.rng_pix, b.rng_st, b.key, g, r_begin,
+                       r_count);
+    FIC_LAUNCH_CHECK();
+    return 0;
+}
+
+// Kernel-variant table of the fast sweep: (B, n_iso) -> <DW, NR, NC>.
+//   B=4 : n_iso 1 -> <4,4,1>    n_iso 8 -> <4,1,8>
+//   B=8 : n_iso 1 -> <16,2,1>   n_iso 8 -> <16,1,8>
+//   B=16: n_iso 1 -> <64,2,1>   n_iso 8 -> <64,1,2> (4 isometry groups on grid.y)
+int fic_fast_variant(int B, int n_iso, int* NR, int* NC)
+{
+    int nr = 0, nc = 0;
+    if (B == 4) { nr = n_iso == 1 ? 4 : 1; nc = n_iso == 1 ? 1 : 8; }
+    else if (B == 8) { nr = n_iso == 1 ? 2 : 1; nc = n_iso == 1 ? 1 : 8; }
+    else if (B == 16) { nr = n_iso == 1 ? 2 : 1; nc = n_iso == 1 ? 1 : 2; }
+    else return -1;
+    if (n_iso != 1 && n_iso != 8) return -1;
+    if (NR) *NR = nr;
+    if (NC) *NC = nc;
+    return 0;
+}
+
+int fic_launch_sweep_fast(const FicBuffers& b, const FicGeom& g, int tile0, int ntiles, int chunk_len, int nchunks,
+                          hipStream_t s)
+{
+    SweepArgs A;
+    A.pool_pix = (const uint32_t*)b.pool_pix;
+    A.pool_st = b.pool_st;
+    A.pool_s64 = b.pool_s64;
+    A.rng_pix = b.rng_pix;
+    A.rng_st = b.rng_st;
+    A.key = b.key;
+    A.Nd = g.Nd; A.Nd_pad = g.Nd_pad; A.Nr = g.Nr; A.Nr_pad = g.Nr_pad; A.n_iso = g.n_iso; A.lgn = g.lgn;
+    A.tile0 = tile0; A.ntiles = ntiles; A.chunk_len = chunk_len; A.nchunks = nchunks;
+    int NR, NC;
+    if (fic_fast_variant(g.B, g.n_iso, &NR, &NC) || NR != g.NR) return -1;
+    dim3 grid((ntiles + 3) / 4, nchunks * (g.n_iso / NC), g.planes);
+    dim3 block(256);
+    if (g.B == 4 && g.n_iso == 1) hipLaunchKernelGGL((k_sweep_fast<4, 4, 1>), grid, block, 0, s, A);
+    else if (g.B == 4) hipLaunchKernelGGL((k_sweep_fast<4, 1, 8>), grid, block, 0, s, A);
+    else if (g.B == 8 && g.n_iso == 1) hipLaunchKernelGGL((k_sweep_fast<16, 2, 1>), grid, block, 0, s, A);
+    else if (g.B == 8) hipLaunchKernelGGL((k_sweep_fast<16, 1, 8>), grid, block, 0, s, A);
+    else if (g.B == 16 && g.n_iso == 1) hipLaunchKernelGGL((k_sweep_fast<64, 2, 1>), grid, block, 0, s, A);
+    else hipLaunchKernelGGL((k_sweep_fast<64, 1, 2>), grid, block, 0, s, A);
+    FIC_LAUNCH_CHECK();
+    return 0;
+}
+
+int fic_launch_finalize(const FicBuffers& b, const FicOutputs& out, const FicGeom& g, int r_begin, int r_count,
+                        hipStream_t s)
+{
+    hipLaunchKernelGGL(k_finalize, dim3((r_count + 255) / 256, g.planes), dim3(256), 0, s, (const uint32_t*)b.pool_pix,
+                       b.pool_st, b.pool_var, b.rng_pix, b.rng_st, b.key, out, g, r_begin, r_count);
+    FIC_LAUNCH_CHECK();
+    return 0;
+}
+
+int fic_launch_collage(const FicBuffers& b, const FicOutputs& out, int32_t* collage, const FicGeom& g, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_collage, dim3((g.W + 255) / 256, g.H, g.planes), dim3(256), 0, s, b.pool_pix, out, collage, g);
+    FIC_LAUNCH_CHECK();
+    return 0;
+}
+
+int fic_launch_sqrt_probe(double* out, uint32_t first, uint32_t count, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_sqrt_probe, dim3((count + 255) / 256), dim3(256), 0, s, out, first, count);
+    FIC_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,50 @@
+// fic_launch.h -- internal: device buffer bundle + kernel launchers (fic_kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "fic_device.h"
+
+// Device-resident working set of one context (all planes of the batch).
+//   pool_pix : u8  [planes][Nd_pad][n]    expanded domain pool, block pixels row-major (FC:1036), 64-B aligned
+//   pool_st  :     [planes][Nd_pad]       {sum, (float)sqrt(var)}  -- streamed beside the pixels
+//   pool_var : u32 [planes][Nd_pad]       Domainblock.variance (exact integer)
+//   pool_s64 : f64 [planes][Nd_pad]       Math.sqrt((double) variance)
+//   rng_pix  : u32 [planes][tiles][NR][n_iso][DW][64]   lane-transposed range blocks + isometry copies
+//   rng_st   :     [planes][Nr_pad]       {rM, rem}
+//   key      : u64 [planes][Nr_pad]       (orderable error << 32) | candidate
+struct FicBuffers {
+    uint8_t* gray;
+    uint8_t* scaled;
+    uint8_t* pool_pix;
+    FicDomStat* pool_st;
+    uint32_t* pool_var;
+    double* pool_s64;
+    uint32_t* rng_pix;
+    FicRngStat* rng_st;
+    unsigned long long* key;
+};
+
+// Per-range results, [planes][Nr] each (qrows: [planes][Nr][3]).
+struct FicOutputs {
+    int32_t* idx_local;   // window-local index  = imageInfo[j][0]   (FC:156, 629)
+    int32_t* idx_global;  // pool index          = calculateIndices  (FC:853-893)
+    int32_t* iso;         // winning isometry (0 when n_iso == 1)
+    float* a;             // unquantised contrast   imageInfo[j][1]
+    float* b;             // unquantised brightness imageInfo[j][2]
+    float* err;           // winning error (diagnostic)
+    int32_t* qrows;       // writeData rows: (int)idx, (int)(a*100), (int)b   (FC:242-244)
+};
+
+int fic_launch_argb_to_gray(const int32_t* argb, uint8_t* gray, size_t npix, hipStream_t s);
+int fic_launch_scale(const uint8_t* gray, uint8_t* scaled, const FicGeom& g, hipStream_t s);
+int fic_launch_pool(const uint8_t* scaled, uint8_t* pool_pix, FicDomStat* st, uint32_t* var, double* s64,
+                    const FicGeom& g, hipStream_t s);
+int fic_launch_range(const uint8_t* gray, uint32_t* rng_pix, FicRngStat* rst, const FicGeom& g, hipStream_t s);
+int fic_launch_sweep_generic(const FicBuffers& b, const FicGeom& g, int r_begin, int r_count, hipStream_t s);
+int fic_fast_variant(int B, int n_iso, int* NR, int* NC);
+int fic_launch_sweep_fast(const FicBuffers& b, const FicGeom& g, int tile0, int ntiles, int chunk_len, int nchunks,
+                          hipStream_t s);
+int fic_launch_finalize(const FicBuffers& b, const FicOutputs& out, const FicGeom& g, int r_begin, int r_count,
+                        hipStream_t s);
+int fic_launch_collage(const FicBuffers& b, const FicOutputs& out, int32_t* collage, const FicGeom& g, hipStream_t s);
+int fic_launch_sqrt_probe(double* out, uint32_t first, uint32_t count, hipStream_t s);

@@ -1,0 +1,40 @@
+"""Synthetic grey inputs of SURVEY.md section 8(d): integer-only, identical in every language.
+
+  U : pix(x,y) = splitmix64(seed + y*W + x) >> 56              iid uniform bytes (throughput)
+  S : 32x32 tiles of levels {0,64,128,192}, alternate tiles carrying 2-bit noise from U --
+      produces flat domain blocks (variance 0), flat ranges (rem 0), exact error ties and
+      NaN fits: the adversarial cases for parity.
+"""
+import numpy as np
+
+SEEDS = {"cfg2": 0xF1C0002, "cfg3": 0xF1C0003, "cfg4": 0xF1C0004, "cfg5": 0xF1C0005}
+_M = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def splitmix64(z):
+    """Output function of SplitMix64 applied to state z (uint64 array)."""
+    with np.errstate(over="ignore"):
+        z = (z + np.uint64(0x9E3779B97F4A7C15)) & _M
+        z = ((z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)) & _M
+        z = ((z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)) & _M
+        return z ^ (z >> np.uint64(31))
+
+
+def image_u(w, h, seed):
+    idx = np.arange(w * h, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        v = splitmix64((idx + np.uint64(seed)) & _M) >> np.uint64(56)
+    return v.astype(np.uint8).reshape(h, w)
+
+
+def image_s(w, h, seed):
+    u = image_u(w, h, seed).astype(np.int32)
+    y, x = np.mgrid[0:h, 0:w]
+    t = (x >> 5) + (y >> 5)
+    noisy = (((x >> 5) ^ (y >> 5)) & 1).astype(bool)
+    s = ((t & 3) << 6) + np.where(noisy, u >> 6, 0)
+    return s.astype(np.uint8)
+
+
+def image(kind, w, h, seed):
+    return image_u(w, h, seed) if kind.upper() == "U" else image_s(w, h, seed)

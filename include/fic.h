@@ -1,0 +1,137 @@
+/*
+ * fic.h -- C ABI of libfic_hip.so: the MI355X (gfx950) drop-in for the grey encode hot path
+ * of bvk_ss19.FractalCompression (LariWa/Fractal-Image-Compression).
+ *
+ * The reference has no FFI seam of its own; the boundary is the body of
+ * FractalCompression.encodeGrayScale between pool build and writeData
+ * (src/bvk_ss19/FractalCompression.java:119-159), reached through
+ * FractalCompression.encode(RasterImage, DataOutputStream) (FractalCompression.java:54).
+ * Each entry point below names the reference code it replaces.  Plain pointers and sizes
+ * only; INTEGRATION.md shows the JNI stub that binds them under the reference's own
+ * Java entry point.
+ *
+ * Conventions
+ *   - every int-returning function returns FIC_OK (0) or a negative FIC_E_* code;
+ *     fic_last_error() then holds a human-readable message for the calling thread.
+ *     The reference throws unchecked exceptions on bad geometry; the JNI
+ *     shim turns a negative code into a thrown java.lang.Exception.
+ *   - the library never retains caller pointers past return.
+ *   - B = FractalCompression.blockgroesse (FractalCompression.java:14), wK =
+ *     FractalCompression.widthKernel (:15).  Supported: B in {4, 8, 16} (the GUI's slider
+ *     values, RLEAppController.java:131), 1 <= wK <= min(Dw, Dh); wK == Dw == Dh is full search.
+ *   - n_iso = 1 is the reference algorithm (bit-identical); n_iso = 8 is this build's
+ *     extension (the 8 isometries of the square; order documented in DESIGN.md).
+ *   - there is NO CPU fallback: without a usable HIP device every compute entry fails
+ *     with FIC_E_NO_DEVICE.
+ */
+#ifndef FIC_H
+#define FIC_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FIC_API __attribute__((visibility("default")))
+
+#define FIC_OK 0
+#define FIC_E_GEOMETRY (-1)    /* W,H,B combination the reference cannot encode (AIOOBE / div-by-zero there) */
+#define FIC_E_WINDOW (-2)      /* wK outside 1..min(Dw,Dh)  (negative index in FractalCompression.java:145) */
+#define FIC_E_ARGUMENT (-3)    /* null pointer, bad n_iso, bad plane/range span ... */
+#define FIC_E_NO_DEVICE (-4)   /* no HIP device / device index out of range */
+#define FIC_E_HIP (-5)         /* a HIP runtime call failed (message has the hipError string) */
+#define FIC_E_NOT_GREY (-6)    /* argb input has r!=g or g!=b somewhere (isGreyScale, FractalCompression.java:32-45) */
+#define FIC_E_STATE (-7)       /* call order: no input set / nothing encoded yet */
+#define FIC_E_CAPACITY (-8)    /* output buffer too small */
+
+typedef struct fic_ctx fic_ctx;
+
+/* ---- library / device ------------------------------------------------------------------ */
+FIC_API const char* fic_version(void);
+FIC_API const char* fic_last_error(void);
+FIC_API int fic_device_count(void);
+
+/* Block-grid geometry exactly as encodeGrayScale derives it (FractalCompression.java:111-116)
+ * and createCodebuch sizes the pool (:1019-1022).  Also the validator: FIC_E_GEOMETRY for
+ * sizes on which the reference throws.  Any out pointer may be NULL. */
+FIC_API int fic_geometry(int w, int h, int B, int* Rw, int* Rh, int* Dw, int* Dh);
+
+/* isGreyScale (FractalCompression.java:32-45) on a host ARGB buffer: 1 grey, 0 colour. */
+FIC_API int fic_is_greyscale_argb(const int32_t* argb, int w, int h);
+
+/* ---- one-shot host-buffer encode (what the JNI shim binds) ------------------------------ */
+/* Replaces the search of encodeGrayScale (FractalCompression.java:119-159): pool build
+ * (createCodebuch :1015-1050), per-range window selection (:128-150), getBestDomainblock
+ * (:613-644) with getErrorVarianceCovariance (:655-687).
+ *   argb      RasterImage.argb, w*h ints, only (argb>>16)&0xff is read (:596, :977)
+ *   idx_local [N_r] imageInfo[j][0] -- window-local candidate index
+ *   a, b      [N_r] imageInfo[j][1..2] -- unquantised float32, bit-exact (needed by
+ *             getBestGeneratedCollage :287); a NaN is returned as 0x7FC00000
+ *   iso       [N_r] winning isometry id, all 0 for n_iso = 1; may be NULL
+ *   qrows     [N_r][3] the ints writeData emits per range (:242-244); may be NULL
+ * device: HIP device ordinal. */
+FIC_API int fic_encode_gray_argb(const int32_t* argb, int w, int h, int B, int wK, int n_iso, int device,
+                                 int32_t* idx_local, float* a, float* b, int32_t* iso, int32_t* qrows);
+/* Same with the R channel already extracted (one byte per pixel, scanline order). */
+FIC_API int fic_encode_gray_u8(const uint8_t* gray, int w, int h, int B, int wK, int n_iso, int device,
+                               int32_t* idx_local, float* a, float* b, int32_t* iso, int32_t* qrows);
+
+/* writeData, grey branch (FractalCompression.java:230-246): big-endian int32 header
+ * {0, w, h, B, wK} then qrows.  Returns bytes written (20 + 12*n_ranges) or a negative code. */
+FIC_API int64_t fic_write_run_gray(const int32_t* qrows, int n_ranges, int w, int h, int B, int wK, uint8_t* out,
+                                   int64_t capacity);
+
+/* ---- handle API: device-resident, batched planes, range shards --------------------------- */
+/* A context owns the working set for `planes` grey images of one geometry on one device
+ * (config 5: 192 planes of 1024x1024; multi-GPU: one context per rank). */
+FIC_API fic_ctx* fic_ctx_create(int device, int w, int h, int B, int wK, int n_iso, int planes);
+FIC_API void fic_ctx_destroy(fic_ctx* ctx);
+
+/* Input: host bytes [planes][h][w] (copied), host ARGB (copied + R extracted on device), or a
+ * device pointer to bytes [planes][h][w] that stays owned by the caller and must remain valid
+ * until fic_ctx_sync (no copy; this is the path bench.py times: inputs resident in HBM). */
+FIC_API int fic_ctx_set_gray_host(fic_ctx* ctx, const uint8_t* gray);
+FIC_API int fic_ctx_set_argb_host(fic_ctx* ctx, const int32_t* argb);
+FIC_API int fic_ctx_set_gray_device(fic_ctx* ctx, const void* dev_gray);
+
+/* Asynchronous encode of range blocks [range_begin, range_begin+range_count) of every plane on
+ * `hip_stream` (a hipStream_t, NULL = default stream): pool build + range prep + sweep +
+ * finalise.  range_count < 0 means "to the end".  Multi-GPU sharding calls this
+ * with a different span per rank; results for other ranges are left untouched. */
+FIC_API int fic_ctx_encode(fic_ctx* ctx, int range_begin, int range_count, void* hip_stream);
+FIC_API int fic_ctx_sync(fic_ctx* ctx);
+
+/* Results.  Host copies are [planes][N_r] ([planes][N_r][3] for qrows); any pointer may be NULL. */
+FIC_API int fic_ctx_get_results_host(fic_ctx* ctx, int32_t* idx_local, float* a, float* b, int32_t* iso,
+                                     int32_t* qrows, int32_t* idx_global, float* err);
+/* Device pointers of the same arrays (for an RCCL gather by the host layer). */
+FIC_API int fic_ctx_result_device_ptrs(fic_ctx* ctx, void** idx_local, void** a, void** b, void** iso, void** qrows,
+                                       void** idx_global, void** err);
+
+/* getBestGeneratedCollage (FractalCompression.java:269-300): grey ARGB [planes][h][w] of the
+ * one-step collage from the unquantised a,b of the last encode (all ranges must be encoded). */
+FIC_API int fic_ctx_collage_host(fic_ctx* ctx, int32_t* argb_out);
+
+/* Tuning / instrumentation knobs:
+ *   "sweep"       0 auto (fast kernel for full search, generic otherwise), 1 generic, 2 fast
+ *   "chunks"      domain-pool chunks per range tile for the fast kernel (0 = auto)
+ *   "time_sweep"  1: bracket every sweep launch with hipEvents on its stream */
+FIC_API int fic_ctx_set_option(fic_ctx* ctx, const char* name, int value);
+/* Sum of sweep-kernel durations (ms) and launch count since the last reset ("time_sweep" = 1).
+ * Synchronises the events.  reset != 0 clears the accumulators afterwards. */
+FIC_API int fic_ctx_sweep_time(fic_ctx* ctx, double* total_ms, int* launches, int reset);
+/* Geometry actually in use: out[0..9] = Rw, Rh, N_r, Dw, Dh, N_d, NR, tiles, chunks, sweep kind. */
+FIC_API int fic_ctx_info(fic_ctx* ctx, int* out10);
+
+/* Test hook: out[i] = sqrt((double)(first + i)) computed on the device exactly as the pool
+ * kernel does for Domainblock.variance (FractalCompression.java:677,680 Math.sqrt). */
+FIC_API int fic_debug_sqrt_f64(int device, uint32_t first, uint32_t count, double* out);
+/* Test hook: copies the pool of the last encode to the host: pix u8 [planes][N_d][n],
+ * sum u32 [planes][N_d], var u32 [planes][N_d], scaled u8 [planes][h/2][w/2]. NULLs allowed. */
+FIC_API int fic_ctx_debug_pool_host(fic_ctx* ctx, uint8_t* pix, uint32_t* sum, uint32_t* var, uint8_t* scaled);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FIC_H */

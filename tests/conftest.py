@@ -1,0 +1,45 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from oracle import fic_oracle
+    fic_oracle.build()
+    fic_oracle.lib()
+    return fic_oracle
+
+
+@pytest.fixture(scope="session")
+def lena_grey():
+    return np.load(os.path.join(GOLDEN, "lena_grey_256.npy"))
+
+
+@pytest.fixture(scope="session")
+def lena64():
+    return np.load(os.path.join(GOLDEN, "lena64.npy"))
+
+
+@pytest.fixture(scope="session")
+def lena_colored():
+    return np.load(os.path.join(GOLDEN, "lena_colored_256.npy"))
+
+
+def same_f32(x, y):
+    """Bit equality of float32 arrays, treating every NaN as equal (Java has one NaN value)."""
+    x = np.ascontiguousarray(x, np.float32)
+    y = np.ascontiguousarray(y, np.float32)
+    nx, ny = np.isnan(x), np.isnan(y)
+    return bool((nx == ny).all() and (x.view(np.uint32)[~nx] == y.view(np.uint32)[~ny]).all())

@@ -1,0 +1,137 @@
+"""CPU-side checks of the product's host layer: the C-ABI library loads and exports every
+symbol include/fic.h declares, validates geometry like the reference would throw, writes the
+.run stream byte-exactly, and refuses to compute without a GPU (no fallback)."""
+import ctypes as C
+import io
+import subprocess
+
+import numpy as np
+import pytest
+
+import fic_amd
+from fic_amd import capi
+
+
+def test_library_exports_every_declared_symbol():
+    names = capi.declared_symbols()
+    assert len(names) >= 20
+    L = C.CDLL(capi.SO_PATH)
+    for n in names:
+        assert hasattr(L, n), f"{n} declared in include/fic.h but not exported"
+    out = subprocess.run(["nm", "-D", "--defined-only", capi.SO_PATH], capture_output=True, text=True).stdout
+    exported = {l.split()[-1] for l in out.splitlines() if " T " in l}
+    assert set(names) <= exported
+    # nothing but the C ABI leaks out of the shared object
+    assert all(s.startswith("fic_") for s in exported), exported - set(names)
+
+
+def test_library_does_not_link_the_oracle():
+    out = subprocess.run(["ldd", capi.SO_PATH], capture_output=True, text=True).stdout
+    assert "oracle" not in out
+    syms = subprocess.run(["nm", "-D", capi.SO_PATH], capture_output=True, text=True).stdout
+    assert "fo_" not in syms
+
+
+def test_geometry_matches_reference_formulas(oracle):
+    for w, h, B in [(64, 64, 4), (256, 256, 8), (256, 256, 16), (512, 512, 8), (2048, 2048, 4), (4096, 4096, 8),
+                    (1024, 1024, 8), (384, 256, 8)]:
+        assert fic_amd.geometry(w, h, B) == oracle.geometry(w, h, B)
+    assert fic_amd.geometry(4096, 4096, 8) == (512, 512, 1021, 1021)
+
+
+@pytest.mark.parametrize("w,h,B", [(510, 512, 8), (512, 511, 8), (12, 12, 8), (8, 8, 8), (64, 64, 2), (64, 64, 12),
+                                   (0, 64, 8), (66, 66, 4 * 5)])
+def test_geometry_rejects_what_the_reference_cannot_encode(w, h, B):
+    with pytest.raises(fic_amd.FicError) as e:
+        fic_amd.geometry(w, h, B)
+    assert e.value.code == -1
+
+
+def test_write_run_gray_bytes(oracle):
+    rng = np.random.default_rng(1)
+    info = np.stack([rng.integers(0, 800, 50).astype(np.float32), rng.uniform(-1, 1, 50).astype(np.float32),
+                     rng.uniform(-300, 300, 50).astype(np.float32)], axis=1)
+    info[3, 1] = np.nan
+    info[3, 2] = np.nan
+    q = oracle.quantise_gray(info)
+    assert (q[3] == [int(info[3, 0]), 0, 0]).all()
+    assert capi.write_run_gray(q, 64, 64, 4, 29) == oracle.write_run_gray(info, 64, 64, 4, 29)
+    with pytest.raises(fic_amd.FicError):
+        out = np.zeros(10, np.uint8)
+        capi.check(int(capi.lib().fic_write_run_gray(capi.ptr(q, C.c_int32), 50, 64, 64, 4, 29,
+                                                     capi.ptr(out, C.c_uint8), out.size)))
+
+
+def test_is_greyscale_mirror(lena_grey, lena_colored, oracle):
+    g = fic_amd.RasterImage.from_gray(lena_grey)
+    assert fic_amd.FractalCompression.isGreyScale(g)
+    c = fic_amd.RasterImage(256, 256, oracle.rgb_to_argb(lena_colored))
+    assert not fic_amd.FractalCompression.isGreyScale(c)
+    assert (g.argb == oracle.gray_to_argb(lena_grey)).all()
+
+
+def test_no_cpu_fallback_without_device(lena64):
+    """In the build container there is no GPU: every compute entry must fail loudly."""
+    if capi.lib().fic_device_count() > 0:
+        pytest.skip("a HIP device is present")
+    with pytest.raises(fic_amd.FicError) as e:
+        fic_amd.encode_gray(lena64, 4)
+    assert "no HIP device" in str(e.value)
+    fc = fic_amd.FractalCompression
+    fc.blockgroesse, fc.widthKernel = 4, 2
+    with pytest.raises(fic_amd.FicError):
+        fc.encode(fic_amd.RasterImage.from_gray(lena64), io.BytesIO())
+    n = 256
+    idx, a, b = np.zeros(n, np.int32), np.zeros(n, np.float32), np.zeros(n, np.float32)
+    rc = capi.lib().fic_encode_gray_u8(capi.ptr(np.ascontiguousarray(lena64), C.c_uint8), 64, 64, 4, 29, 1, 0,
+                                       capi.ptr(idx, C.c_int32), capi.ptr(a, C.c_float), capi.ptr(b, C.c_float),
+                                       None, None)
+    assert rc == -4
+
+
+def test_rgb_dispatch_is_loud(lena_colored, oracle):
+    c = fic_amd.RasterImage(256, 256, oracle.rgb_to_argb(lena_colored))
+    with pytest.raises(NotImplementedError):
+        fic_amd.FractalCompression.encode(c, io.BytesIO())
+
+
+def test_shard_spans_cover_and_align():
+    for nr, tile, world in [(4096, 64, 8), (262144, 64, 8), (262144, 128, 8), (400, 128, 3), (256, 256, 4), (1024, 64, 1)]:
+        spans = fic_amd.shard_spans(nr, tile, world)
+        assert len(spans) == world
+        pos = 0
+        for b, c in spans:
+            assert b == pos or c == 0
+            assert b % tile == 0 or c == 0
+            pos = b + c if c else pos
+        assert pos == nr
+    assert fic_amd.shard_planes(192, 8) == [(24 * r, 24) for r in range(8)]
+
+
+def test_synthetic_images_are_pinned():
+    """Known answers so that any other-language generator can be checked against the same bytes."""
+    u = fic_amd.synth.image_u(8, 2, 1)
+    assert u.tolist() == [[145, 151, 29, 110, 99, 189, 99, 158], [174, 8, 80, 148, 196, 106, 135, 93]]
+    s = fic_amd.synth.image_s(128, 64, fic_amd.synth.SEEDS["cfg2"])
+    assert s.shape == (64, 128) and s.dtype == np.uint8
+    assert (s[:32, :32] == 0).all() and s[0, 32] in (64, 65, 66, 67) and (s[32:, 32:64] == 128).all()
+    import hashlib
+    assert hashlib.sha256(fic_amd.synth.image_u(512, 512, fic_amd.synth.SEEDS["cfg2"]).tobytes()).hexdigest()[:16] == \
+        hashlib.sha256(fic_amd.synth.image_u(512, 512, 0xF1C0002).tobytes()).hexdigest()[:16]
+
+
+def test_pack_unpack_records_roundtrip():
+    rng = np.random.default_rng(0)
+    P, N = 2, 100
+    res = {"idx_local": rng.integers(0, 1000, (P, N)).astype(np.int32),
+           "a": rng.uniform(-1, 1, (P, N)).astype(np.float32), "b": rng.uniform(-300, 300, (P, N)).astype(np.float32),
+           "iso": rng.integers(0, 8, (P, N)).astype(np.int32), "qrows": rng.integers(-300, 300, (P, N, 3)).astype(np.int32)}
+    res["qrows"][..., 0] = res["idx_local"]
+    res["a"][0, 5] = np.nan
+    rec = fic_amd.pack_records(res, 10, 50)
+    assert rec.shape == (P, 50, 6)
+    back = fic_amd.unpack_records(rec)
+    for k in ("idx_local", "iso", "qrows"):
+        assert (back[k] == res[k][:, 10:60]).all()
+    assert (back["a"].view(np.uint32) == res["a"][:, 10:60].view(np.uint32)).all()
+    assert (back["b"].view(np.uint32) == res["b"][:, 10:60].view(np.uint32)).all()
