@@ -44,7 +44,10 @@ WORKLOADS = {
 }
 
 HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-VALU_LANE_OPS = 256 * 4 * 32 * 2.4e9   # 256 CU x 4 SIMD-32 x 2.4 GHz lane-instructions/s
+# Measured on MI355X (profiles/r01_valu_issue_rate_microbench.txt): v_dot4_u32_u8 -- like v_mad_i32_i24,
+# v_cvt_*, v_cmp_* and any VALU op with an SGPR source -- issues one wave64 instruction per 4 cycles
+# per SIMD (only plain v_fma_f32 / v_add_u32 reach 2 cycles).  Peak for this kernel's instruction mix:
+VALU_WAVE_INSTR_PEAK = 256 * 4 * 2.4e9 / 4.0   # wave-instructions/s, chip-wide, at the 2.4 GHz max clock
 
 
 def cpu_baseline(wl, img, budget_s=12.0):
@@ -181,7 +184,7 @@ def main():
         # VALU instructions per pair evaluation of the sweep kernel (static count from the ISA):
         # n/4 v_dot4 + cvt + cmp per isometry copy, + 3 per (range,domain) shared by the copies
         valu_per_eval = n / 4 + 2 + 3.0 / (n_iso if n_iso > 1 else 1)
-        valu_frac = pair_evals * valu_per_eval / (avg_ms * 1e-3) / VALU_LANE_OPS
+        valu_frac = pair_evals * valu_per_eval / 64.0 / (avg_ms * 1e-3) / VALU_WAVE_INSTR_PEAK
         out = {
             "metric": "range-block matches/sec (8x8 R, 16x16 D, 8 iso)" if (B == 8 and n_iso == 8) else
                       f"range-block matches/sec ({B}x{B} R, {2 * B}x{2 * B} D, {n_iso} iso)",
@@ -200,8 +203,11 @@ def main():
                          "note": "algorithmic bytes = ranges x N_d x (n+8); each wave keeps 64 range blocks in VGPRs "
                                  "and reads a pool block once for all of them, so frac > 1 means the sweep is past the "
                                  "HBM roofline and bounded by VALU issue instead (see valu)"},
-            "valu": {"bound": "valu-issue", "achieved_frac": valu_frac, "valu_instr_per_pair_eval": valu_per_eval,
-                     "peak_lane_ops_per_s": VALU_LANE_OPS},
+            "valu": {"bound": "valu-issue (the true bound of this kernel)", "frac": valu_frac,
+                     "valu_instr_per_pair_eval": valu_per_eval, "peak_wave_instr_per_s": VALU_WAVE_INSTR_PEAK,
+                     "note": "peak = 1 wave64 VALU instruction / 4 cycles / SIMD x 1024 SIMDs x 2.4 GHz, the measured "
+                             "issue rate of v_dot4_u32_u8 (profiles/r01_valu_issue_rate_microbench.txt); PMC: "
+                             "SQ_ACTIVE_INST_VALU = 96% of kernel cycles (profiles/r01a_cfg2_pmc_summary.txt)"},
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(wl, imgs[0], args.cpu_budget)

@@ -48,6 +48,7 @@ def lib():
     sig = {
         "fic_version": (C.c_char_p, []),
         "fic_last_error": (C.c_char_p, []),
+        "fic_last_error_code": (C.c_int, []),
         "fic_device_count": (C.c_int, []),
         "fic_geometry": (C.c_int, [C.c_int, C.c_int, C.c_int, ip, ip, ip, ip]),
         "fic_is_greyscale_argb": (C.c_int, [i32p, C.c_int, C.c_int]),

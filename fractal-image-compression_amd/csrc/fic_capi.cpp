@@ -16,6 +16,7 @@
 namespace {
 
 thread_local std::string g_err;
+thread_local int g_err_code = 0;
 
 int fail(int code, const char* fmt, ...)
 {
@@ -25,6 +26,7 @@ int fail(int code, const char* fmt, ...)
     vsnprintf(buf, sizeof(buf), fmt, ap);
     va_end(ap);
     g_err = buf;
+    g_err_code = code;
     return code;
 }
 
@@ -144,6 +146,7 @@ extern "C" {
 
 const char* fic_version(void) { return "fic-hip 0.1 (gfx950)"; }
 const char* fic_last_error(void) { return g_err.c_str(); }
+int fic_last_error_code(void) { return g_err_code; }
 
 int fic_device_count(void)
 {
@@ -314,9 +317,9 @@ int fic_ctx_encode(fic_ctx* c, int range_begin, int range_count, void* hip_strea
     const int tile0 = range_begin / tsz;
     const int tile1 = (range_begin + range_count + tsz - 1) / tsz;
     const int ntiles = tile1 - tile0;
-    for (int p = 0; p < g.planes; p++)
-        HIP_TRY(hipMemsetAsync(c->b.key + (size_t)p * g.Nr_pad + (size_t)tile0 * tsz, 0xFF,
-                               (size_t)ntiles * tsz * sizeof(unsigned long long), s));
+    // one 2-D fill: rows = planes (pitch Nr_pad keys), width = the tile span of this shard
+    HIP_TRY(hipMemset2DAsync(c->b.key + (size_t)tile0 * tsz, (size_t)g.Nr_pad * sizeof(unsigned long long), 0xFF,
+                             (size_t)ntiles * tsz * sizeof(unsigned long long), (size_t)g.planes, s));
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (c->opt_time) {
         HIP_TRY(hipEventCreate(&e0));
@@ -498,19 +501,15 @@ static int encode_oneshot(const uint8_t* gray, const int32_t* argb, int w, int h
 {
     if ((!gray && !argb) || !idx_local || !a || !b) return fail(FIC_E_ARGUMENT, "fic_encode_gray: null argument");
     fic_ctx* c = fic_ctx_create(device, w, h, B, wK, n_iso, 1);
-    if (!c) {
-        // fic_ctx_create already set the message; recover its code from the text class
-        FicGeom g;
-        int rc = make_geometry(w, h, B, wK, n_iso, 1, &g);
-        if (rc) return rc;
-        return fic_device_count() > 0 && device >= 0 && device < fic_device_count() ? FIC_E_HIP : FIC_E_NO_DEVICE;
-    }
+    if (!c) return g_err_code ? g_err_code : FIC_E_HIP;   // fic_ctx_create recorded why
     int rc = gray ? fic_ctx_set_gray_host(c, gray) : fic_ctx_set_argb_host(c, argb);
     if (rc == FIC_OK) rc = fic_ctx_encode(c, 0, -1, nullptr);
     if (rc == FIC_OK) rc = fic_ctx_get_results_host(c, idx_local, a, b, iso, qrows, nullptr, nullptr);
     std::string keep = g_err;
+    int keep_code = g_err_code;
     fic_ctx_destroy(c);
     g_err = keep;
+    g_err_code = keep_code;
     return rc;
 }
 

@@ -65,7 +65,7 @@ class Encoder:
         self.n_ranges, self.n_domains = Rw * Rh, Dw * Dh
         self._h = L.fic_ctx_create(device, width, height, B, wK, n_iso, planes)
         if not self._h:
-            raise FicError(-3, capi.last_error())
+            raise FicError(L.fic_last_error_code() or -3, capi.last_error())
         self._keep = None
         info = (C.c_int * 10)()
         capi.check(L.fic_ctx_info(self._h, info))

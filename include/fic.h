@@ -50,6 +50,7 @@ typedef struct fic_ctx fic_ctx;
 /* ---- library / device ------------------------------------------------------------------ */
 FIC_API const char* fic_version(void);
 FIC_API const char* fic_last_error(void);
+FIC_API int fic_last_error_code(void);   /* code of the last failure on this thread (for NULL returns) */
 FIC_API int fic_device_count(void);
 
 /* Block-grid geometry exactly as encodeGrayScale derives it (FractalCompression.java:111-116)
