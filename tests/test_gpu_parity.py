@@ -293,3 +293,26 @@ def test_iso8_never_worse_than_iso1_and_decodes(oracle):
     run = fic_amd.write_run_gray(e1["qrows"], 256, 256, 8, 61)
     img, avg, iters = oracle.decode_gray(run)
     assert abs(oracle.psnr(img, g) - 24.823) < 1e-3     # decoded PSNR of SURVEY table row 7
+
+
+def test_cpp_host_mirror_of_the_java_entry_point(oracle, tmp_path):
+    """include/fic_host.hpp: bvk_ss19::FractalCompression::encode(RasterImage, ostream) driven like
+    RLEAppController.openDecodedImage (CTL:172-188) -- .run bytes and collage equal the oracle's."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(GOLDEN), "cpp", "host_mirror_test")
+    if not os.path.exists(exe):
+        pytest.fail("tests/cpp/host_mirror_test missing: run __graft_entry__.build()")
+    g = IMAGES["lena256"]
+    raw = tmp_path / "g.raw"
+    raw.write_bytes(g.tobytes())
+    for B, wK in [(8, 2), (8, 61), (4, 16)]:
+        run, col = tmp_path / f"o{B}_{wK}.run", tmp_path / f"c{B}_{wK}.raw"
+        subprocess.check_call([exe, str(raw), "256", "256", str(B), str(wK), str(run), str(col)])
+        ref = _oracle_encode(oracle, g, B, wK, 1)
+        assert run.read_bytes() == oracle.write_run_gray(ref["info"], 256, 256, B, wK)
+        want = oracle.collage_gray(oracle.gray_to_argb(g), 256, 256, B, wK, ref["info"])
+        assert (np.frombuffer(col.read_bytes(), np.int32) == want).all()
+    # bad geometry -> exception (exit code 1), like the reference's unchecked exceptions
+    rc = subprocess.call([exe, str(raw), "256", "256", "8", "200", str(tmp_path / "x.run"), str(tmp_path / "x.raw")],
+                         stderr=subprocess.DEVNULL)
+    assert rc == 1
