@@ -65,6 +65,8 @@ def lib():
         "fic_ctx_get_results_host": (C.c_int, [vp, i32p, f32p, f32p, i32p, i32p, i32p, f32p]),
         "fic_ctx_result_device_ptrs": (C.c_int, [vp] + [C.POINTER(vp)] * 7),
         "fic_ctx_collage_host": (C.c_int, [vp, i32p]),
+        "fic_decode_gray_run": (C.c_int, [u8p, C.c_int64, C.c_int, u8p, C.c_int64, ip, ip, f32p, ip]),
+        "fic_ctx_decode_host": (C.c_int, [vp, u8p, f32p, ip]),
         "fic_ctx_set_option": (C.c_int, [vp, C.c_char_p, C.c_int]),
         "fic_ctx_sweep_time": (C.c_int, [vp, C.POINTER(C.c_double), ip, C.c_int]),
         "fic_ctx_info": (C.c_int, [vp, ip]),
@@ -97,6 +99,23 @@ def geometry(w, h, B):
     v = [C.c_int() for _ in range(4)]
     check(lib().fic_geometry(w, h, B, *[C.byref(x) for x in v]))
     return tuple(x.value for x in v)
+
+
+def decode_gray_run(run, device=0, avg_error_in=0.0):
+    """FractalCompression.decode on a grey .run stream (FC:547-553, 356-421), on the GPU.
+    Returns (gray uint8 [H,W], avgError float32 after the call, iterations)."""
+    buf = np.frombuffer(bytes(run), np.uint8)
+    if buf.size < 20:
+        raise FicError(-3, "run stream shorter than its header")
+    w = int.from_bytes(bytes(run[4:8]), "big", signed=True)
+    h = int.from_bytes(bytes(run[8:12]), "big", signed=True)
+    cap = max(w, 0) * max(h, 0)
+    out = np.zeros(max(cap, 1), np.uint8)
+    avg = C.c_float(avg_error_in)
+    it, wo, ho = C.c_int(), C.c_int(), C.c_int()
+    check(lib().fic_decode_gray_run(ptr(buf, C.c_uint8), buf.size, device, ptr(out, C.c_uint8), cap, C.byref(wo),
+                                    C.byref(ho), C.byref(avg), C.byref(it)))
+    return out[:cap].reshape(h, w), np.float32(avg.value), it.value
 
 
 def write_run_gray(qrows, w, h, B, wK):

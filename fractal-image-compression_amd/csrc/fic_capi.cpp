@@ -92,6 +92,7 @@ struct fic_ctx {
     uint8_t* gray_own = nullptr;     // context-owned input copy
     int32_t* argb_stage = nullptr;   // staging for ARGB uploads
     int32_t* collage = nullptr;
+    uint8_t* decoded = nullptr;      // decoder output image(s)
     bool have_input = false;
     bool encoded_any = false;
     hipStream_t last_stream = nullptr;
@@ -117,7 +118,7 @@ int ctx_free_all(fic_ctx* c)
     hipSetDevice(c->device);
     for (hipEvent_t e : c->ev) hipEventDestroy(e);
     c->ev.clear();
-    void* ptrs[] = {c->gray_own, c->argb_stage, c->collage, c->b.scaled, c->b.pool_pix, c->b.pool_st, c->b.pool_var,
+    void* ptrs[] = {c->gray_own, c->argb_stage, c->collage, c->decoded, c->b.scaled, c->b.pool_pix, c->b.pool_st, c->b.pool_var,
                     c->b.pool_s64, c->b.rng_pix, c->b.rng_st, c->b.key, c->o.idx_local, c->o.idx_global, c->o.iso,
                     c->o.a, c->o.b, c->o.err, c->o.qrows};
     for (void* p : ptrs)
@@ -494,6 +495,108 @@ int fic_ctx_debug_pool_host(fic_ctx* c, uint8_t* pix, uint32_t* sum, uint32_t* v
     }
     if (scaled) HIP_TRY(hipMemcpy(scaled, c->b.scaled, (size_t)g.planes * g.Ws * g.Hs, hipMemcpyDeviceToHost));
     return FIC_OK;
+}
+
+// ---- decoder (decodeGreyScale FC:356-421) ------------------------------------------------------
+// Runs the reconstruction loop on the device.  Iterations are enqueued in groups of 8 and the
+// per-plane loop state is read back after each group (a converging decode takes 6-7 iterations),
+// so there is one host sync per group, none per iteration.
+static int run_decode_loop(const FicGeom& g, uint8_t* d_scaled, uint8_t* d_image, const int32_t* d_qrows,
+                           const int32_t* d_iso, const float* avg_in, float* avg_out, int* iters_out, hipStream_t s)
+{
+    const size_t P = (size_t)g.planes;
+    FicDecodeState* d_state = nullptr;
+    HIP_TRY(hipMalloc((void**)&d_state, P * sizeof(FicDecodeState)));
+    std::vector<FicDecodeState> st(P);
+    memset(st.data(), 0, P * sizeof(FicDecodeState));
+    for (size_t p = 0; p < P; p++) st[p].avg = avg_in ? avg_in[p] : 0.0f;   // static avgError is never reset (FC:20)
+    int rc = FIC_OK;
+    hipError_t e = hipMemcpyAsync(d_state, st.data(), P * sizeof(FicDecodeState), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemsetAsync(d_image, 128, P * g.W * g.H, s);        // generateGrayImage FC:1142-1148
+    if (e != hipSuccess) rc = fail(FIC_E_HIP, "decode init: %s", hipGetErrorString(e));
+    for (int counter = 0; rc == FIC_OK && counter < 50; counter++) {
+        if (fic_launch_decode_iteration(d_scaled, d_image, d_qrows, d_iso, d_state, counter, g, s)) {
+            rc = fail(FIC_E_HIP, "decode iteration launch failed");
+            break;
+        }
+        if ((counter & 7) == 7 || counter == 49) {
+            e = hipMemcpyAsync(st.data(), d_state, P * sizeof(FicDecodeState), hipMemcpyDeviceToHost, s);
+            if (e == hipSuccess) e = hipStreamSynchronize(s);
+            if (e != hipSuccess) { rc = fail(FIC_E_HIP, "decode readback: %s", hipGetErrorString(e)); break; }
+            bool all = true;
+            for (size_t p = 0; p < P; p++) all = all && st[p].done;
+            if (all) break;
+        }
+    }
+    hipFree(d_state);
+    if (rc != FIC_OK) return rc;
+    for (size_t p = 0; p < P; p++) {
+        if (st[p].bad_index)
+            return fail(FIC_E_ARGUMENT, "decode: a codebook row of plane %zu points outside the domain pool "
+                                        "(ArrayIndexOutOfBounds at FC:394 in the reference)", p);
+        if (avg_out) avg_out[p] = st[p].avg_out;
+        if (iters_out) iters_out[p] = st[p].iters;
+    }
+    return FIC_OK;
+}
+
+int fic_ctx_decode_host(fic_ctx* c, uint8_t* gray_out, float* avg_error_out, int* iterations_out)
+{
+    if (!c || !gray_out) return fail(FIC_E_ARGUMENT, "fic_ctx_decode_host: null argument");
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (!c->encoded_any) return fail(FIC_E_STATE, "fic_ctx_decode_host: nothing encoded yet");
+    HIP_TRY(hipSetDevice(c->device));
+    const FicGeom& g = c->g;
+    size_t npix = (size_t)g.planes * g.W * g.H;
+    if (!c->decoded) { int rc = dev_alloc(&c->decoded, npix); if (rc) return rc; }
+    HIP_TRY(hipStreamSynchronize(c->last_stream));
+    int rc = run_decode_loop(g, c->b.scaled, c->decoded, c->o.qrows, g.n_iso > 1 ? c->o.iso : nullptr, nullptr,
+                             avg_error_out, iterations_out, c->last_stream);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(gray_out, c->decoded, npix, hipMemcpyDeviceToHost));
+    return FIC_OK;
+}
+
+int fic_decode_gray_run(const uint8_t* run, int64_t len, int device, uint8_t* gray_out, int64_t capacity, int* w_out,
+                        int* h_out, float* avg_error_io, int* iterations)
+{
+    if (!run || len < 20) return fail(FIC_E_ARGUMENT, "fic_decode_gray_run: stream shorter than the 20-byte header");
+    auto be = [&](int64_t off) {
+        return (int32_t)(((uint32_t)run[off] << 24) | ((uint32_t)run[off + 1] << 16) | ((uint32_t)run[off + 2] << 8) |
+                         (uint32_t)run[off + 3]);
+    };
+    if (be(0) != 0) return fail(FIC_E_NOT_GREY, "fic_decode_gray_run: isRGB = %d (FC:548-552 dispatches to decodeRGB)", be(0));
+    const int w = be(4), h = be(8), B = be(12), wK = be(16);
+    FicGeom g;
+    int rc = make_geometry(w, h, B, wK, 1, 1, &g);
+    if (rc) return rc;
+    if (w_out) *w_out = w;
+    if (h_out) *h_out = h;
+    if (len < 20 + 12 * (int64_t)g.Nr)
+        return fail(FIC_E_ARGUMENT, "fic_decode_gray_run: %lld bytes, need %lld (EOFException in the reference)",
+                    (long long)len, (long long)(20 + 12 * (int64_t)g.Nr));
+    if (!gray_out || capacity < (int64_t)w * h) return fail(FIC_E_CAPACITY, "fic_decode_gray_run: output needs %d bytes", w * h);
+    int ndev = fic_device_count();
+    if (ndev <= 0 || device < 0 || device >= ndev) return fail(FIC_E_NO_DEVICE, "no HIP device %d (this library has no CPU path)", device);
+    HIP_TRY(hipSetDevice(device));
+    std::vector<int32_t> q((size_t)g.Nr * 3);
+    for (size_t i = 0; i < q.size(); i++) q[i] = be(20 + 4 * (int64_t)i);          // FC:372-374
+    uint8_t *d_scaled = nullptr, *d_image = nullptr;
+    int32_t* d_q = nullptr;
+    hipError_t e = hipMalloc((void**)&d_scaled, (size_t)g.Ws * g.Hs);
+    if (e == hipSuccess) e = hipMalloc((void**)&d_image, (size_t)w * h);
+    if (e == hipSuccess) e = hipMalloc((void**)&d_q, q.size() * 4);
+    if (e == hipSuccess) e = hipMemcpy(d_q, q.data(), q.size() * 4, hipMemcpyHostToDevice);
+    if (e != hipSuccess) rc = fail(FIC_E_HIP, "fic_decode_gray_run: %s", hipGetErrorString(e));
+    float avg = avg_error_io ? *avg_error_io : 0.0f;
+    if (rc == FIC_OK) rc = run_decode_loop(g, d_scaled, d_image, d_q, nullptr, &avg, &avg, iterations, nullptr);
+    if (rc == FIC_OK) {
+        e = hipMemcpy(gray_out, d_image, (size_t)w * h, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = fail(FIC_E_HIP, "fic_decode_gray_run: %s", hipGetErrorString(e));
+    }
+    if (rc == FIC_OK && avg_error_io) *avg_error_io = avg;
+    hipFree(d_scaled); hipFree(d_image); hipFree(d_q);
+    return rc;
 }
 
 static int encode_oneshot(const uint8_t* gray, const int32_t* argb, int w, int h, int B, int wK, int n_iso, int device,

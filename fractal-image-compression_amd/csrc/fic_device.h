@@ -41,3 +41,14 @@ struct FicRngStat {
 // Candidate key: (orderable f32 error) << 32 | candidate index.  Unsigned min over
 // keys == Java's strict '<' scan in ascending candidate order (FC:619-632).
 #define FIC_KEY_NONE 0xFFFFFFFFFFFFFFFFull
+
+// Per-plane decoder state (decodeGreyScale FC:381-418), device resident.
+struct FicDecodeState {
+    unsigned long long ssd[50];   // exact sum (range - value)^2 of each iteration
+    float avg;                    // FractalCompression.avgError carried INTO the next iteration (FC:407,416)
+    float avg_out;                // avgError after the last executed iteration (what CTL:180 displays)
+    int iters;                    // iterations executed
+    int done;                     // loop ended (avgError < 1, FC:414, or counter == 49)
+    int bad_index;                // a row pointed outside the pool (Java: ArrayIndexOutOfBounds at FC:394)
+    int pad;
+};

@@ -48,3 +48,7 @@ int fic_launch_finalize(const FicBuffers& b, const FicOutputs& out, const FicGeo
                         hipStream_t s);
 int fic_launch_collage(const FicBuffers& b, const FicOutputs& out, int32_t* collage, const FicGeom& g, hipStream_t s);
 int fic_launch_sqrt_probe(double* out, uint32_t first, uint32_t count, hipStream_t s);
+
+// decoder (FC:356-421)
+int fic_launch_decode_iteration(uint8_t* scaled, uint8_t* image, const int32_t* qrows, const int32_t* iso,
+                                FicDecodeState* state, int counter, const FicGeom& g, hipStream_t s);

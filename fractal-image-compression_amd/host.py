@@ -168,6 +168,17 @@ class Encoder:
         capi.check(capi.lib().fic_ctx_collage_host(self._h, capi.ptr(out, C.c_int32)))
         return out
 
+    def decode(self):
+        """Reference decoder loop (FC:356-421) on the device from the last encode's quantised rows
+        (+ isometries).  Returns (gray uint8 [planes,H,W], avgError float32 [planes], iterations int32 [planes])."""
+        P = self.planes
+        out = np.zeros((P, self.height, self.width), np.uint8)
+        avg = np.zeros(P, np.float32)
+        it = np.zeros(P, np.int32)
+        capi.check(capi.lib().fic_ctx_decode_host(self._h, capi.ptr(out, C.c_uint8), capi.ptr(avg, C.c_float),
+                                                  capi.ptr(it, C.c_int)))
+        return out, avg, it
+
     def debug_pool(self):
         P, Nd, n = self.planes, self.n_domains, self.B * self.B
         pix = np.zeros((P, Nd, n), np.uint8)
@@ -220,6 +231,21 @@ class FractalCompression:
         if cls.isGreyScale(image):
             return cls.encodeGrayScale(image, out)
         return cls.encodeRGB(image, out)
+
+    avgError = np.float32(0.0)   # FC:20 -- static, never reset between decode calls
+
+    @classmethod
+    def getAvgError(cls):   # FC:22-24
+        return cls.avgError
+
+    @classmethod
+    def decode(cls, inputStream):   # FC:547-553
+        data = inputStream.read() if hasattr(inputStream, "read") else bytes(inputStream)
+        if len(data) >= 4 and int.from_bytes(data[:4], "big", signed=True) != 0:
+            raise NotImplementedError("decodeRGB (FC:430-508) is not GPU-backed yet")
+        gray, avg, _ = capi.decode_gray_run(data, cls.device, float(cls.avgError))
+        cls.avgError = avg
+        return RasterImage.from_gray(gray)
 
     @classmethod
     def encodeRGB(cls, image, out):   # FC:171-219 -- joint-RGB path, SURVEY 8(f) "next #1"

@@ -114,6 +114,25 @@ FIC_API int fic_ctx_result_device_ptrs(fic_ctx* ctx, void** idx_local, void** a,
  * one-step collage from the unquantised a,b of the last encode (all ranges must be encoded). */
 FIC_API int fic_ctx_collage_host(fic_ctx* ctx, int32_t* argb_out);
 
+/* ---- decoder --------------------------------------------------------------------------------- */
+/* FractalCompression.decode on a complete grey .run stream (FractalCompression.java:547-553 ->
+ * decodeGreyScale :356-421): header, rows, calculateIndices (:853-893), then up to 50 iterations
+ * of {rebuild pool from the current image, repaint every range block, accumulate the squared
+ * change}, stopping when the mean change drops below 1 (:413-415).
+ *   gray_out        R channel of the decoded image, w*h bytes (the reference returns grey ARGB)
+ *   avg_error_io    in: FractalCompression.avgError before the call (the static is never reset,
+ *                   :20,:407); out: its value after the call = the GUI's "MSE" label
+ *                   (RLEAppController.java:180).  May be NULL (treated as 0).
+ *   iterations      iterations executed; may be NULL.
+ * The per-iteration sum is an exact integer on the device; it equals Java's float accumulation
+ * whenever it is below 2^24, which holds for the iteration that ends a converging decode. */
+FIC_API int fic_decode_gray_run(const uint8_t* run, int64_t len, int device, uint8_t* gray_out, int64_t capacity,
+                                int* w, int* h, float* avg_error_io, int* iterations);
+/* The same loop driven from the context's last encode: quantised rows (and isometry ids, so
+ * n_iso = 8 codebooks decode too) stay on the device.  gray_out [planes][h][w]; avg_error_out and
+ * iterations_out [planes], may be NULL.  Every range block must have been encoded. */
+FIC_API int fic_ctx_decode_host(fic_ctx* ctx, uint8_t* gray_out, float* avg_error_out, int* iterations_out);
+
 /* Tuning / instrumentation knobs:
  *   "sweep"       0 auto (fast kernel for full search, generic otherwise), 1 generic, 2 fast
  *   "chunks"      domain-pool chunks per range tile for the fast kernel (0 = auto)

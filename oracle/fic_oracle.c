@@ -535,6 +535,61 @@ FO_API int fo_decode_gray(const uint8_t* run, int64_t len, int32_t* out_argb, in
     return 0;
 }
 
+/* ---- decoder for the n_iso = 8 extension --------------------------------------------------
+ * Same loop as fo_decode_gray, driven from quantised rows {i_local,(int)(a*100),(int)b} plus an
+ * isometry id per range: the domain pixel is read through iso_k (out[y][x] = d[sy][sx]).
+ * With iso == NULL (or all zero) it must equal fo_decode_gray bit for bit (tested). */
+FO_API int fo_decode_rows(const int32_t* qrows, const int32_t* iso, int width, int height, int B, int wK,
+                          int32_t* out_argb, float* avg_error_io, int* iters_out)
+{
+    int Rw, Rh, Dw, Dh;
+    int rc = fo_geometry(width, height, B, &Rw, &Rh, &Dw, &Dh);
+    if (rc) return rc;
+    int nr = Rw * Rh, n = B * B;
+    for (int i = 0; i < width * height; i++) out_argb[i] = grey_argb(128);
+    float* imgData = (float*)malloc(sizeof(float) * 3 * (size_t)nr);
+    for (int rows = 0; rows < nr; rows++) {
+        imgData[3 * rows + 0] = (float)qrows[3 * rows + 0];
+        imgData[3 * rows + 1] = (float)qrows[3 * rows + 1] / 100.0f;
+        imgData[3 * rows + 2] = (float)qrows[3 * rows + 2];
+    }
+    fo_calculate_indices(imgData, 3, width, height, B, wK);
+    float avgError = avg_error_io ? *avg_error_io : 0.0f;
+    int iters = 0;
+    for (int counter = 0; counter < 50; counter++) {
+        fo_codebook cb;
+        rc = fo_create_codebuch(out_argb, width, height, B, &cb);
+        if (rc) { fo_codebook_free(&cb); free(imgData); return rc; }
+        int i = 0;
+        for (int y = 0; y < height; y += B)
+            for (int x = 0; x < width; x += B) {
+                int g = fo_java_f2i(imgData[3 * i + 0]);
+                if (g < 0 || g >= cb.count) { fo_codebook_free(&cb); free(imgData); return -24; }
+                int k = iso ? iso[i] : 0;
+                for (int ry = 0; ry < B; ry++)
+                    for (int rx = 0; rx < B; rx++) {
+                        int range = red(out_argb[x + rx + (y + ry) * width]);
+                        int domain = cb.pix[(size_t)g * n + fo_iso_source(k, B, rx, ry)];
+                        int value = fo_java_f2i(imgData[3 * i + 1] * (float)domain + imgData[3 * i + 2]);
+                        if (value < 0) value = 0;
+                        else if (value > 255) value = 255;
+                        out_argb[x + rx + (y + ry) * width] = grey_argb(value);
+                        avgError += (float)((range - value) * (range - value));
+                    }
+                i++;
+            }
+        fo_codebook_free(&cb);
+        iters = counter + 1;
+        avgError = avgError / (float)(width * height);
+        if (avgError < 1) break;
+        if (counter != 49) avgError = 0;
+    }
+    free(imgData);
+    if (avg_error_io) *avg_error_io = avgError;
+    if (iters_out) *iters_out = iters;
+    return 0;
+}
+
 /* ---- getBestGeneratedCollage FC:269-300 -------------------------------------- */
 /* info is float[N_r][3] as produced by the encoder (local idx, unquantised a,b).
  * Like the reference it MUTATES info[.][0] to the global index (FC:273). */

@@ -144,6 +144,24 @@ def decode_gray(run, avg_error_in=0.0):
     return gray, np.float32(avg.value), iters.value
 
 
+def decode_rows(qrows, iso, w, h, B, wK, avg_error_in=0.0):
+    """Decoder loop from quantised rows + isometry ids (n_iso = 8 extension twin of decode_gray)."""
+    L = lib()
+    L.fo_decode_rows.argtypes = [C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int, C.c_int, C.c_int, C.c_int,
+                                 C.POINTER(C.c_int32), C.POINTER(C.c_float), C.POINTER(C.c_int)]
+    q = np.ascontiguousarray(qrows, np.int32)
+    k = None if iso is None else np.ascontiguousarray(iso, np.int32)
+    out = np.zeros(w * h, np.int32)
+    avg = C.c_float(avg_error_in)
+    iters = C.c_int()
+    rc = L.fo_decode_rows(_p(q, C.c_int32), None if k is None else _p(k, C.c_int32), w, h, B, wK, _p(out, C.c_int32),
+                          C.byref(avg), C.byref(iters))
+    if rc:
+        raise ValueError(f"fo_decode_rows rc={rc}")
+    gray = ((out.view(np.uint32) >> 16) & 0xFF).astype(np.uint8).reshape(h, w)
+    return gray, np.float32(avg.value), iters.value
+
+
 def collage_gray(argb, w, h, B, wK, info):
     info = np.ascontiguousarray(info, np.float32).copy()
     out = np.zeros(w * h, np.int32)

@@ -316,3 +316,80 @@ def test_cpp_host_mirror_of_the_java_entry_point(oracle, tmp_path):
     rc = subprocess.call([exe, str(raw), "256", "256", "8", "200", str(tmp_path / "x.run"), str(tmp_path / "x.raw")],
                          stderr=subprocess.DEVNULL)
     assert rc == 1
+
+
+DECODE_CASES = [("lena256", 8, 16), ("lena256", 16, 16), ("lena256", 4, 16), ("lena256", 8, 8), ("lena256", 8, 4),
+                ("lena256", 8, 2), ("lena256", 8, 61), ("lena64", 4, 29), ("lena64", 4, 2), ("S128", 8, 29),
+                ("U128", 4, 8), ("wide", 8, 5), ("tall", 16, 3), ("flat64", 8, 13)]
+
+
+@pytest.mark.parametrize("name,B,wK", DECODE_CASES)
+def test_gpu_decoder_matches_reference_decoder(oracle, name, B, wK):
+    """FractalCompression.decode (FC:547-553, 356-421) on the GPU: image, avgError bits and
+    iteration count equal the oracle's restatement of the Java loop."""
+    g = IMAGES[name]
+    h, w = g.shape
+    ref = _oracle_encode(oracle, g, B, wK, 1)
+    run = oracle.write_run_gray(ref["info"], w, h, B, wK)
+    want_img, want_avg, want_it = oracle.decode_gray(run)
+    img, avg, it = fic_amd.decode_gray_run(run)
+    assert it == want_it
+    assert (img == want_img).all()
+    assert np.float32(avg).view(np.uint32) == np.float32(want_avg).view(np.uint32)
+
+
+@pytest.mark.parametrize("case", K2, ids=[f"B{c['B']}_wK{c['wK']}" for c in K2])
+def test_k2_gui_labels_entirely_on_the_gpu(case):
+    """Encode AND decode on the GPU through the drop-in mirror, landing on the reference GUI's label."""
+    fc = fic_amd.FractalCompression
+    fc.blockgroesse, fc.widthKernel, fc.n_iso = case["B"], case["wK"], 1
+    fc.avgError = np.float32(0.0)
+    out = io.BytesIO()
+    fc.encode(fic_amd.RasterImage.from_gray(IMAGES["lena256"]), out)
+    img = fc.decode(io.BytesIO(out.getvalue()))
+    assert fc.getAvgError() == np.float32(case["mse_label"])
+    assert img.width == 256 and img.height == 256
+    fc.blockgroesse, fc.widthKernel = 8, 2
+
+
+def test_decoder_static_avg_error_carry_over(oracle):
+    """FractalCompression.avgError is never reset (FC:20,407): a second decode starts from the first one's value."""
+    g = IMAGES["lena256"]
+    ref = _oracle_encode(oracle, g, 8, 16, 1)
+    run = oracle.write_run_gray(ref["info"], 256, 256, 8, 16)
+    _, a1, _ = oracle.decode_gray(run)
+    _, a2, i2 = oracle.decode_gray(run, float(a1))
+    _, g1, _ = fic_amd.decode_gray_run(run)
+    _, g2, j2 = fic_amd.decode_gray_run(run, 0, float(g1))
+    assert g1 == a1 and g2 == a2 and i2 == j2
+
+
+def test_decoder_rejects_what_the_reference_cannot_read():
+    with pytest.raises(fic_amd.FicError):
+        fic_amd.decode_gray_run(b"\x00" * 10)
+    hdr = b"".join(int(v).to_bytes(4, "big", signed=True) for v in (0, 64, 64, 4, 29))
+    with pytest.raises(fic_amd.FicError):          # rows missing: EOFException in the reference
+        fic_amd.decode_gray_run(hdr + b"\x00" * 100)
+    rows = np.zeros((256, 3), ">i4")
+    rows[:, 0] = 29 * 29 + 5                       # index outside the pool: AIOOBE at FC:394
+    with pytest.raises(fic_amd.FicError):
+        fic_amd.decode_gray_run(hdr + rows.tobytes())
+    rgb = b"".join(int(v).to_bytes(4, "big", signed=True) for v in (1, 64, 64, 4, 29))
+    with pytest.raises(fic_amd.FicError):
+        fic_amd.decode_gray_run(rgb + b"\x00" * 5120)
+
+
+@pytest.mark.parametrize("n_iso", [1, 8])
+def test_context_decode_with_isometries_and_batches(oracle, n_iso):
+    imgs = [IMAGES["lena256"], synth.image_s(256, 256, 5), synth.image_u(256, 256, 6)]
+    with fic_amd.Encoder(256, 256, 8, None, n_iso, planes=3) as enc:
+        enc.set_gray(np.stack(imgs))
+        enc.encode()
+        r = enc.results()
+        dec, avg, it = enc.decode()
+    for p, g in enumerate(imgs):
+        want, wavg, wit = oracle.decode_rows(r["qrows"][p], r["iso"][p] if n_iso > 1 else None, 256, 256, 8, 61)
+        assert (dec[p] == want).all() and it[p] == wit
+        assert avg[p].view(np.uint32) == np.float32(wavg).view(np.uint32)
+    if n_iso == 1:
+        assert abs(oracle.psnr(dec[0], imgs[0]) - 24.823) < 1e-3

@@ -99,3 +99,16 @@ def test_scale_quirk_uses_height(oracle):
     s = ((out.view(np.uint32) >> 16) & 0xFF).reshape(h // 2, w // 2)
     assert (s[:, :3] == 200).all()            # x+1 < 8
     assert (s[:, 4:] == (600 + 128) // 4).all()  # x+1 >= 8
+
+
+def test_decode_rows_twin_equals_literal_decoder(oracle, lena_grey):
+    """fo_decode_rows (the isometry-aware twin used for n_iso = 8) == fo_decode_gray when iso is absent."""
+    argb = oracle.gray_to_argb(lena_grey)
+    for B, wK in [(8, 16), (16, 16), (8, 2)]:
+        e = oracle.encode_gray(argb, 256, 256, B, wK)
+        run = oracle.write_run_gray(e["info"], 256, 256, B, wK)
+        a = oracle.decode_gray(run)
+        b = oracle.decode_rows(oracle.quantise_gray(e["info"]), None, 256, 256, B, wK)
+        c = oracle.decode_rows(oracle.quantise_gray(e["info"]), np.zeros(e["info"].shape[0], np.int32), 256, 256, B, wK)
+        for x in (b, c):
+            assert (x[0] == a[0]).all() and x[1] == a[1] and x[2] == a[2]
