@@ -65,6 +65,8 @@ def lib():
         "fic_ctx_get_results_host": (C.c_int, [vp, i32p, f32p, f32p, i32p, i32p, i32p, f32p]),
         "fic_ctx_result_device_ptrs": (C.c_int, [vp] + [C.POINTER(vp)] * 7),
         "fic_ctx_collage_host": (C.c_int, [vp, i32p]),
+        "fic_encode_rgb_argb": (C.c_int, [i32p] + [C.c_int] * 5 + [i32p, f32p, f32p, f32p, f32p, i32p, i32p]),
+        "fic_write_run_rgb": (C.c_int64, [i32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, u8p, C.c_int64]),
         "fic_decode_gray_run": (C.c_int, [u8p, C.c_int64, C.c_int, u8p, C.c_int64, ip, ip, f32p, ip]),
         "fic_ctx_decode_host": (C.c_int, [vp, u8p, f32p, ip]),
         "fic_ctx_set_option": (C.c_int, [vp, C.c_char_p, C.c_int]),
@@ -116,6 +118,34 @@ def decode_gray_run(run, device=0, avg_error_in=0.0):
     check(lib().fic_decode_gray_run(ptr(buf, C.c_uint8), buf.size, device, ptr(out, C.c_uint8), cap, C.byref(wo),
                                     C.byref(ho), C.byref(avg), C.byref(it)))
     return out[:cap].reshape(h, w), np.float32(avg.value), it.value
+
+
+def encode_rgb(argb, w, h, B, wK, device=0, want_collage=False):
+    """encodeRGB (FC:171-219) on the GPU.  argb: int32 [h*w].  Returns a dict of [N_r] arrays
+    (idx_local, a, bR, bG, bB, qrows [N_r,5]) and, when asked, the collage (int32 [h*w])."""
+    Rw, Rh, Dw, Dh = geometry(w, h, B)
+    nr = Rw * Rh
+    argb = np.ascontiguousarray(argb, np.int32).reshape(-1)
+    if argb.size != w * h:
+        raise FicError(-3, "argb has the wrong number of pixels")
+    r = {"idx_local": np.zeros(nr, np.int32), "a": np.zeros(nr, np.float32), "bR": np.zeros(nr, np.float32),
+         "bG": np.zeros(nr, np.float32), "bB": np.zeros(nr, np.float32), "qrows": np.zeros((nr, 5), np.int32)}
+    col = np.zeros(w * h, np.int32) if want_collage else None
+    check(lib().fic_encode_rgb_argb(ptr(argb, C.c_int32), w, h, B, wK, device, ptr(r["idx_local"], C.c_int32),
+                                    ptr(r["a"], C.c_float), ptr(r["bR"], C.c_float), ptr(r["bG"], C.c_float),
+                                    ptr(r["bB"], C.c_float), ptr(r["qrows"], C.c_int32), ptr(col, C.c_int32)))
+    if want_collage:
+        r["collage"] = col
+    return r
+
+
+def write_run_rgb(qrows5, w, h, B, wK):
+    """writeData RGB branch (FC:230-238, 248-257): header + 5 ints per row, big-endian."""
+    q = np.ascontiguousarray(qrows5, np.int32).reshape(-1, 5)
+    out = np.zeros(20 + 20 * q.shape[0], np.uint8)
+    n = lib().fic_write_run_rgb(ptr(q, C.c_int32), q.shape[0], w, h, B, wK, ptr(out, C.c_uint8), out.size)
+    check(int(n))
+    return out.tobytes()
 
 
 def write_run_gray(qrows, w, h, B, wK):

@@ -599,6 +599,79 @@ int fic_decode_gray_run(const uint8_t* run, int64_t len, int device, uint8_t* gr
     return rc;
 }
 
+// ---- joint-RGB encode (encodeRGB FC:171-219) -----------------------------------------------------
+int fic_encode_rgb_argb(const int32_t* argb, int w, int h, int B, int wK, int device, int32_t* idx_local, float* a,
+                        float* bR, float* bG, float* bB, int32_t* qrows5, int32_t* collage_argb)
+{
+    if (!argb || !idx_local || !a || !bR || !bG || !bB) return fail(FIC_E_ARGUMENT, "fic_encode_rgb_argb: null argument");
+    FicGeom g;
+    int rc = make_geometry(w, h, B, wK, 1, 1, &g);
+    if (rc) return rc;
+    int ndev = fic_device_count();
+    if (ndev <= 0 || device < 0 || device >= ndev) return fail(FIC_E_NO_DEVICE, "no HIP device %d (this library has no CPU path)", device);
+    HIP_TRY(hipSetDevice(device));
+    FicRgbBuffers b;
+    FicRgbOutputs o;
+    memset(&b, 0, sizeof(b));
+    memset(&o, 0, sizeof(o));
+    int32_t* d_collage = nullptr;
+    const size_t npix = (size_t)w * h, nr = (size_t)g.Nr, nd = (size_t)g.Nd, n = (size_t)g.n;
+    hipError_t e = hipSuccess;
+    auto M = [&](void** p, size_t bytes) { if (e == hipSuccess) e = hipMalloc(p, bytes); };
+    M((void**)&b.argb, npix * 4);
+    M((void**)&b.scaled, (size_t)g.Ws * g.Hs * 4);
+    M((void**)&b.pool_sum, nd * n * 2);
+    M((void**)&b.pool_st, nd * sizeof(FicRgbDomStat));
+    M((void**)&b.rng_t, nr * n * 2);
+    M((void**)&b.rng_st, nr * sizeof(FicRgbRngStat));
+    M((void**)&b.key, nr * 8);
+    M((void**)&o.idx_local, nr * 4);
+    M((void**)&o.idx_global, nr * 4);
+    M((void**)&o.a, nr * 4);
+    M((void**)&o.bR, nr * 4);
+    M((void**)&o.bG, nr * 4);
+    M((void**)&o.bB, nr * 4);
+    M((void**)&o.qrows, nr * 20);
+    if (collage_argb) M((void**)&d_collage, npix * 4);
+    if (e == hipSuccess) e = hipMemcpy(b.argb, argb, npix * 4, hipMemcpyHostToDevice);
+    if (e != hipSuccess) rc = fail(FIC_E_HIP, "fic_encode_rgb_argb: %s", hipGetErrorString(e));
+    if (rc == FIC_OK && fic_launch_rgb_encode(b, o, d_collage, g, nullptr)) rc = fail(FIC_E_HIP, "RGB kernel launch failed");
+    auto D = [&](void* dst, const void* src, size_t bytes) {
+        if (rc == FIC_OK && dst) {
+            hipError_t e2 = hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost);
+            if (e2 != hipSuccess) rc = fail(FIC_E_HIP, "fic_encode_rgb_argb: %s", hipGetErrorString(e2));
+        }
+    };
+    D(idx_local, o.idx_local, nr * 4);
+    D(a, o.a, nr * 4);
+    D(bR, o.bR, nr * 4);
+    D(bG, o.bG, nr * 4);
+    D(bB, o.bB, nr * 4);
+    D(qrows5, o.qrows, nr * 20);
+    D(collage_argb, d_collage, npix * 4);
+    void* ptrs[] = {b.argb, b.scaled, b.pool_sum, b.pool_st, b.rng_t, b.rng_st, b.key, o.idx_local, o.idx_global,
+                    o.a, o.bR, o.bG, o.bB, o.qrows, d_collage};
+    for (void* p : ptrs)
+        if (p) hipFree(p);
+    return rc;
+}
+
+int64_t fic_write_run_rgb(const int32_t* qrows5, int n_ranges, int w, int h, int B, int wK, uint8_t* out, int64_t capacity)
+{
+    if (!qrows5 || !out || n_ranges < 0) return fail(FIC_E_ARGUMENT, "fic_write_run_rgb: bad argument");
+    int64_t need = 20 + 20 * (int64_t)n_ranges;
+    if (capacity < need) return fail(FIC_E_CAPACITY, "fic_write_run_rgb: need %lld bytes, have %lld", (long long)need, (long long)capacity);
+    auto put = [](uint8_t* p, int32_t v) {
+        uint32_t u = (uint32_t)v;
+        p[0] = (uint8_t)(u >> 24); p[1] = (uint8_t)(u >> 16); p[2] = (uint8_t)(u >> 8); p[3] = (uint8_t)u;
+    };
+    const int32_t hdr[5] = {1, w, h, B, wK};          // FC:234-238, isRGB = 1
+    for (int i = 0; i < 5; i++) put(out + 4 * i, hdr[i]);
+    uint8_t* p = out + 20;
+    for (int64_t i = 0; i < 5 * (int64_t)n_ranges; i++, p += 4) put(p, qrows5[i]);   // FC:249-256
+    return need;
+}
+
 static int encode_oneshot(const uint8_t* gray, const int32_t* argb, int w, int h, int B, int wK, int n_iso, int device,
                           int32_t* idx_local, float* a, float* b, int32_t* iso, int32_t* qrows)
 {

@@ -52,3 +52,18 @@ struct FicDecodeState {
     int bad_index;                // a row pointed outside the pool (Java: ArrayIndexOutOfBounds at FC:394)
     int pad;
 };
+
+// Joint-RGB path (encodeRGB FC:171-219).  Per domain block:
+//   msum  = mittelWertR + mittelWertG + mittelWertB            (DB:33-39)
+//   vD    = sum_i greyD_i = varianzDomain after the loop        (FC:778-791; Domainblock.variance stays 0)
+//   varsq = varianceR + varianceG + mittelWertB  (sic, f32)     (FC:776)
+struct FicRgbDomStat {
+    int32_t msum, vD;
+    float varsq;
+    int32_t mR, mG, mB;
+    int32_t pad0, pad1;
+};
+// Per range block: channel means (FC:771-773) and vR = sum_i greyR_i = varianzRange (FC:790).
+struct FicRgbRngStat {
+    int32_t mR, mG, mB, vR;
+};

@@ -49,6 +49,28 @@ int fic_launch_finalize(const FicBuffers& b, const FicOutputs& out, const FicGeo
 int fic_launch_collage(const FicBuffers& b, const FicOutputs& out, int32_t* collage, const FicGeom& g, hipStream_t s);
 int fic_launch_sqrt_probe(double* out, uint32_t first, uint32_t count, hipStream_t s);
 
+// joint-RGB encode (FC:171-219): per-range results, [N_r] each (qrows: [N_r][5], FC:250-254)
+struct FicRgbOutputs {
+    int32_t* idx_local;
+    int32_t* idx_global;
+    float* a;
+    float* bR;
+    float* bG;
+    float* bB;
+    int32_t* qrows;
+};
+struct FicRgbBuffers {
+    int32_t* argb;           // input [H][W]
+    int32_t* scaled;         // [H/2][W/2] packed ARGB
+    uint16_t* pool_sum;      // [N_d][n]  R+G+B per domain pixel
+    FicRgbDomStat* pool_st;  // [N_d]
+    int16_t* rng_t;          // [N_r][n]  greyR_i
+    FicRgbRngStat* rng_st;   // [N_r]
+    unsigned long long* key; // [N_r]
+};
+int fic_launch_rgb_encode(const FicRgbBuffers& b, const FicRgbOutputs& out, int32_t* collage, const FicGeom& g,
+                          hipStream_t s);
+
 // decoder (FC:356-421)
 int fic_launch_decode_iteration(uint8_t* scaled, uint8_t* image, const int32_t* qrows, const int32_t* iso,
                                 FicDecodeState* state, int counter, const FicGeom& g, hipStream_t s);

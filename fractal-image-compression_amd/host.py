@@ -247,10 +247,17 @@ class FractalCompression:
         cls.avgError = avg
         return RasterImage.from_gray(gray)
 
+    imageInfoRGB = None       # float32 [N_r][5] = {i_local, a, bR, bG, bB}   (FC:18,185)
+    _lastRGB = None
+
     @classmethod
-    def encodeRGB(cls, image, out):   # FC:171-219 -- joint-RGB path, SURVEY 8(f) "next #1"
-        raise NotImplementedError("encodeRGB: the joint-RGB encode is not built yet; "
-                                  "only the grey path (FC:109-162) is GPU-backed")
+    def encodeRGB(cls, image, out):   # FC:171-219
+        B, wK = cls.blockgroesse, cls.widthKernel
+        r = capi.encode_rgb(image.argb, image.width, image.height, B, wK, cls.device, want_collage=True)
+        cls.imageInfoRGB = np.stack([r["idx_local"].astype(np.float32), r["a"], r["bR"], r["bG"], r["bB"]], axis=1)
+        cls._lastRGB = {"qrows": r["qrows"]}
+        cls.writeData(out, 1, image.width, image.height)              # FC:217
+        return RasterImage(image.width, image.height, r["collage"])    # FC:218
 
     @classmethod
     def encodeGrayScale(cls, image, out):   # FC:109-162
@@ -268,8 +275,13 @@ class FractalCompression:
 
     @classmethod
     def writeData(cls, out, isRGB, width, height):   # FC:230-261
-        if isRGB != 0:
-            raise NotImplementedError("writeData: RGB branch (FC:248-257) not built yet")
+        if isRGB != 0:                                               # FC:248-257
+            if cls._lastRGB is None:
+                raise FicError(-7, "writeData before encode")
+            out.write(capi.write_run_rgb(cls._lastRGB["qrows"], width, height, cls.blockgroesse, cls.widthKernel))
+            if hasattr(out, "close") and not isinstance(out, io.BytesIO):
+                out.close()
+            return
         if cls._last is None:
             raise FicError(-7, "writeData before encode")
         run = capi.write_run_gray(cls._last["qrows"], width, height, cls.blockgroesse, cls.widthKernel)

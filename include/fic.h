@@ -114,6 +114,20 @@ FIC_API int fic_ctx_result_device_ptrs(fic_ctx* ctx, void** idx_local, void** a,
  * one-step collage from the unquantised a,b of the last encode (all ranges must be encoded). */
 FIC_API int fic_ctx_collage_host(fic_ctx* ctx, int32_t* argb_out);
 
+/* ---- joint-RGB encode ------------------------------------------------------------------------- */
+/* encodeRGB (FractalCompression.java:171-219), what FractalCompression.encode dispatches to for
+ * colour input (:55-58): scaleImageRGB (:901-962), createCodebuchRGB (:1058-1093) + Domainblock RGB
+ * ctor (Domainblock.java:30-41), getBestDomainblockRGB (:697-735), getErrorVarianceCovarianceRGB
+ * (:760-808).  One contrast `a` for the three channels, three brightness values.
+ *   idx_local, a, bR, bG, bB  [N_r] = imageInfoRGB[j][0..4], unquantised float32 (NaN as 0x7FC00000)
+ *   qrows5        [N_r][5] the ints writeData emits (:250-254); may be NULL
+ *   collage_argb  getBestGeneratedCollageRGB (:308-347), w*h ARGB ints; may be NULL */
+FIC_API int fic_encode_rgb_argb(const int32_t* argb, int w, int h, int B, int wK, int device, int32_t* idx_local,
+                                float* a, float* bR, float* bG, float* bB, int32_t* qrows5, int32_t* collage_argb);
+/* writeData, RGB branch (FractalCompression.java:230-238, 248-257): header {1,w,h,B,wK} + 5 ints per row. */
+FIC_API int64_t fic_write_run_rgb(const int32_t* qrows5, int n_ranges, int w, int h, int B, int wK, uint8_t* out,
+                                  int64_t capacity);
+
 /* ---- decoder --------------------------------------------------------------------------------- */
 /* FractalCompression.decode on a complete grey .run stream (FractalCompression.java:547-553 ->
  * decodeGreyScale :356-421): header, rows, calculateIndices (:853-893), then up to 50 iterations

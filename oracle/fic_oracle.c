@@ -822,6 +822,37 @@ FO_API int fo_encode_rgb(const int32_t* argb, int w, int h, int B, int wK, float
     return 0;
 }
 
+/* getBestGeneratedCollageRGB FC:308-347; info float[N_r][5], its column 0 is mutated to the global index */
+FO_API int fo_collage_rgb(const int32_t* argb, int w, int h, int B, int wK, float* info, int32_t* out_argb)
+{
+    int rc = fo_geometry(w, h, B, 0, 0, 0, 0);
+    if (rc) return rc;
+    fo_calculate_indices(info, 5, w, h, B, wK);
+    fo_codebook_rgb cb;
+    rc = fo_create_codebuch_rgb(argb, w, h, B, &cb);
+    if (rc) { fo_codebook_rgb_free(&cb); return rc; }
+    int n = B * B, i = 0;
+    for (int y = 0; y < h; y += B)
+        for (int x = 0; x < w; x += B) {
+            int g = fo_java_f2i(info[5 * i + 0]);
+            for (int ry = 0; ry < B && y + ry < h; ry++)
+                for (int rx = 0; rx < B && x + rx < w; rx++) {
+                    int32_t d = cb.argb[(size_t)g * n + rx + ry * B];
+                    int vR = fo_java_f2i(info[5 * i + 1] * (float)red(d) + info[5 * i + 2]);
+                    int vG = fo_java_f2i(info[5 * i + 1] * (float)green(d) + info[5 * i + 3]);
+                    int vB = fo_java_f2i(info[5 * i + 1] * (float)blue(d) + info[5 * i + 4]);
+                    vR = vR < 0 ? 0 : (vR > 255 ? 255 : vR);
+                    vG = vG < 0 ? 0 : (vG > 255 ? 255 : vG);
+                    vB = vB < 0 ? 0 : (vB > 255 ? 255 : vB);
+                    out_argb[x + rx + (y + ry) * w] =
+                        (int32_t)(0xff000000u | ((uint32_t)vR << 16) | ((uint32_t)vG << 8) | (uint32_t)vB);
+                }
+            i++;
+        }
+    fo_codebook_rgb_free(&cb);
+    return 0;
+}
+
 /* writeData, RGB branch FC:248-257 */
 FO_API int64_t fo_write_run_rgb(const float* info, int n_ranges, int w, int h, int B, int wK, uint8_t* out)
 {

@@ -187,6 +187,24 @@ def encode_rgb(argb, w, h, B, wK):
     return info
 
 
+def collage_rgb(argb, w, h, B, wK, info):
+    L = lib()
+    L.fo_collage_rgb.argtypes = [C.POINTER(C.c_int32), C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float),
+                                 C.POINTER(C.c_int32)]
+    info = np.ascontiguousarray(info, np.float32).copy()
+    out = np.zeros(w * h, np.int32)
+    argb = np.ascontiguousarray(argb, np.int32)
+    rc = L.fo_collage_rgb(_p(argb, C.c_int32), w, h, B, wK, _p(info, C.c_float), _p(out, C.c_int32))
+    if rc:
+        raise ValueError(f"fo_collage_rgb rc={rc}")
+    return out
+
+
+def quantise_rgb(info):
+    run = write_run_rgb(info, 0, 0, 0, 0)
+    return np.frombuffer(run[20:], dtype=">i4").astype(np.int32).reshape(-1, 5)
+
+
 def write_run_rgb(info, w, h, B, wK):
     info = np.ascontiguousarray(info, np.float32)
     nr = info.shape[0]

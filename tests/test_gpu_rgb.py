@@ -1,0 +1,88 @@
+"""Joint-RGB encode on the GPU (encodeRGB FC:171-219) against the K1-pinned oracle -- and K1 itself:
+the reference's own committed encoder output unknown.run, reproduced byte for byte by the GPU."""
+import hashlib
+import io
+import os
+
+import numpy as np
+import pytest
+
+import fic_amd
+from fic_amd import synth
+from conftest import GOLDEN, same_f32
+
+pytestmark = pytest.mark.gpu
+
+
+def _rgb_synth(w, h, seed, flat=False):
+    """Integer-only synthetic colour image: three U planes (S planes when flat=True)."""
+    f = synth.image_s if flat else synth.image_u
+    return np.stack([f(w, h, seed), f(w, h, seed + 1), f(w, h, seed + 2)], axis=-1)
+
+
+def _check(oracle, rgb, B, wK):
+    h, w = rgb.shape[:2]
+    argb = oracle.rgb_to_argb(rgb)
+    ref = oracle.encode_rgb(argb, w, h, B, wK)
+    got = fic_amd.encode_rgb(argb, w, h, B, wK, want_collage=True)
+    assert (got["idx_local"] == ref[:, 0].astype(np.int32)).all()
+    for k, col in (("a", 1), ("bR", 2), ("bG", 3), ("bB", 4)):
+        assert same_f32(got[k], ref[:, col]), k
+    assert (got["qrows"] == oracle.quantise_rgb(ref)).all()
+    assert fic_amd.write_run_rgb(got["qrows"], w, h, B, wK) == oracle.write_run_rgb(ref, w, h, B, wK)
+    assert (got["collage"] == oracle.collage_rgb(argb, w, h, B, wK, ref)).all()
+    return got
+
+
+def test_k1_unknown_run_reproduced_by_the_gpu(lena_colored, oracle):
+    """K1: LenaColored.jpg, B=8, wK=2 (the GUI defaults) -> the reference's committed unknown.run."""
+    ref = open(os.path.join(GOLDEN, "unknown_run.bin"), "rb").read()
+    argb = oracle.rgb_to_argb(lena_colored)
+    got = fic_amd.encode_rgb(argb, 256, 256, 8, 2)
+    run = fic_amd.write_run_rgb(got["qrows"], 256, 256, 8, 2)
+    assert run == ref
+    assert hashlib.sha256(run).hexdigest().startswith("940ad9d6")
+
+
+def test_k1_through_the_drop_in_entry_point(lena_colored, oracle):
+    """FractalCompression.encode(colour RasterImage, out) dispatches to encodeRGB (FC:55-58)."""
+    fc = fic_amd.FractalCompression
+    fc.blockgroesse, fc.widthKernel = 8, 2
+    img = fic_amd.RasterImage(256, 256, oracle.rgb_to_argb(lena_colored))
+    out = io.BytesIO()
+    collage = fc.encode(img, out)
+    assert out.getvalue() == open(os.path.join(GOLDEN, "unknown_run.bin"), "rb").read()
+    ref = oracle.encode_rgb(img.argb, 256, 256, 8, 2)
+    assert (collage.argb == oracle.collage_rgb(img.argb, 256, 256, 8, 2, ref)).all()
+    assert same_f32(fc.imageInfoRGB, ref)
+
+
+@pytest.mark.parametrize("B,wK", [(8, 2), (8, 4), (8, 16), (4, 2), (4, 16), (16, 2), (16, 8), (8, 61), (16, 29)])
+def test_lena_colored_windows_and_full_search(lena_colored, oracle, B, wK):
+    _check(oracle, lena_colored, B, wK)
+
+
+@pytest.mark.parametrize("B,wK,flat", [(8, 2, False), (8, 29, False), (4, 5, True), (8, 29, True), (16, 13, True), (4, 61, False)])
+def test_synthetic_colour_images(oracle, B, wK, flat):
+    _check(oracle, _rgb_synth(128, 128, 77, flat), B, wK)
+
+
+def test_non_square_and_extremes(oracle):
+    _check(oracle, _rgb_synth(192, 128, 5, True), 8, 5)          # W > H: the FC:940 height quirk
+    _check(oracle, _rgb_synth(128, 192, 6), 8, 3)
+    sat = np.zeros((64, 64, 3), np.uint8)
+    sat[::2, :, 0] = 255
+    sat[:, ::2, 1] = 255
+    sat[32:, :, 2] = 255                                          # large |greyR*greyD| sums: f32 accumulation order
+    _check(oracle, sat, 16, 5)
+    _check(oracle, sat, 8, 13)
+    _check(oracle, np.full((64, 64, 3), (10, 200, 30), np.uint8), 8, 13)   # constant colour: 0/0 fits
+
+
+def test_rgb_errors():
+    argb = np.zeros(64 * 64, np.int32)
+    with pytest.raises(fic_amd.FicError) as e:
+        fic_amd.encode_rgb(argb, 64, 64, 8, 14)
+    assert e.value.code == -2
+    with pytest.raises(fic_amd.FicError):
+        fic_amd.encode_rgb(argb, 64, 62, 8, 2)

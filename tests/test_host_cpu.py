@@ -90,9 +90,24 @@ def test_no_cpu_fallback_without_device(lena64):
 
 
 def test_rgb_dispatch_is_loud(lena_colored, oracle):
+    """Colour input dispatches to encodeRGB (FC:55-58), which is GPU-backed: no device -> loud failure."""
+    if capi.lib().fic_device_count() > 0:
+        pytest.skip("a HIP device is present")
     c = fic_amd.RasterImage(256, 256, oracle.rgb_to_argb(lena_colored))
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(fic_amd.FicError) as e:
         fic_amd.FractalCompression.encode(c, io.BytesIO())
+    assert e.value.code == -4
+    with pytest.raises(fic_amd.FicError):
+        fic_amd.decode_gray_run(b"\x00" * 20 + b"\x00" * 12)
+
+
+def test_write_run_rgb_bytes(oracle):
+    rng = np.random.default_rng(2)
+    info = np.stack([rng.integers(0, 4, 40).astype(np.float32)] + [rng.uniform(-1, 1, 40).astype(np.float32)] +
+                    [rng.uniform(-300, 300, 40).astype(np.float32) for _ in range(3)], axis=1)
+    info[7, 1:] = np.nan
+    q = oracle.quantise_rgb(info)
+    assert capi.write_run_rgb(q, 256, 256, 8, 2) == oracle.write_run_rgb(info, 256, 256, 8, 2)
 
 
 def test_shard_spans_cover_and_align():
