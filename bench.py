@@ -84,6 +84,8 @@ def main():
     ap.add_argument("--planes", type=int, default=None, help="override images per GPU (weak) / total (strong)")
     ap.add_argument("--n-iso", type=int, default=None, choices=[1, 8])
     ap.add_argument("--chunks", type=int, default=0)
+    ap.add_argument("--sweep", type=int, default=0, choices=[0, 2, 3],
+                    help="0/2 = VALU sweep k_sweep_fast (default, north_star's design); 3 = opt-in matrix-core sweep")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=12.0)
     args = ap.parse_args()
@@ -134,6 +136,8 @@ def main():
     core.set_option("time_sweep", 1)
     if args.chunks:
         core.set_option("chunks", args.chunks)
+    if args.sweep:
+        core.set_option("sweep", args.sweep)
     stream = torch.cuda.current_stream()
     res_dev = core.results_device()
 
@@ -209,6 +213,20 @@ def main():
                              "issue rate of v_dot4_u32_u8 (profiles/r01_valu_issue_rate_microbench.txt); PMC: "
                              "SQ_ACTIVE_INST_VALU = 96% of kernel cycles (profiles/r01a_cfg2_pmc_summary.txt)"},
         }
+        if info["sweep_kind"] == 3:
+            # opt-in matrix-core sweep: the inner products run on v_mfma_i32_32x32x32_i8 (dense i8 peak = 2x bf16
+            # = 5.0 PetaOP/s, MI355X_MICROARCH.md "Matrix cores"); its VALU epilogue is ~3.5 instr per pair-eval.
+            ops = pair_evals * 2.0 * n
+            out["dtype"] = "i8 MFMA -> i32 (exact), f32/f64 epilogue"
+            out["roofline_hbm_logical"] = dict(out["roofline"], kernel="k_sweep_mfma")
+            out["roofline"] = {"bound": "mfma", "achieved": ops / (avg_ms * 1e-3) / 1e12, "peak": 5000.0,
+                               "unit": "TOP/s", "frac": ops / (avg_ms * 1e-3) / 1e12 / 5000.0, "traffic": None,
+                               "kernel": "k_sweep_mfma", "avg_launch_ms": avg_ms, "launches": sweep_n,
+                               "note": "opt-in (--sweep 3): north_star rules MFMA out for this path; default is the VALU sweep"}
+            vpe = 3.5
+            out["valu"] = {"bound": "valu-issue (epilogue)", "valu_instr_per_pair_eval": vpe,
+                           "frac": pair_evals * vpe / 64.0 / (avg_ms * 1e-3) / VALU_WAVE_INSTR_PEAK,
+                           "peak_wave_instr_per_s": VALU_WAVE_INSTR_PEAK}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(wl, imgs[0], args.cpu_budget)
         else:

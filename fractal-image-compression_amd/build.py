@@ -15,7 +15,9 @@ HEADERS = ["fic_device.h", "fic_launch.h", os.path.join("..", "..", "include", "
 # -ffp-contract=off: the Java reference never fuses a*b+c (FractalCompression.java:641,683);
 # hipcc's device default is "fast".  No fast-math: f32 divide/sqrt stay correctly rounded.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
-         "-fvisibility=hidden", "-Wno-unused-value"]
+         "-fvisibility=hidden", "-Wno-unused-value",
+         # MFMA results straight into VGPRs (gfx950's register file is unified): no v_accvgpr_read per element
+         "-mllvm", "-amdgpu-mfma-vgpr-form"]
 
 
 def _hipcc():

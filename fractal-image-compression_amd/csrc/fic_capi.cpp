@@ -93,6 +93,9 @@ struct fic_ctx {
     int32_t* argb_stage = nullptr;   // staging for ARGB uploads
     int32_t* collage = nullptr;
     uint8_t* decoded = nullptr;      // decoder output image(s)
+    void* mfma_poolB = nullptr;      // opt-in matrix-core sweep: B fragments, A fragments, range constants
+    void* mfma_rngA = nullptr;
+    int* mfma_rconst = nullptr;
     bool have_input = false;
     bool encoded_any = false;
     hipStream_t last_stream = nullptr;
@@ -118,7 +121,7 @@ int ctx_free_all(fic_ctx* c)
     hipSetDevice(c->device);
     for (hipEvent_t e : c->ev) hipEventDestroy(e);
     c->ev.clear();
-    void* ptrs[] = {c->gray_own, c->argb_stage, c->collage, c->decoded, c->b.scaled, c->b.pool_pix, c->b.pool_st, c->b.pool_var,
+    void* ptrs[] = {c->gray_own, c->argb_stage, c->collage, c->decoded, c->mfma_poolB, c->mfma_rngA, c->mfma_rconst, c->b.scaled, c->b.pool_pix, c->b.pool_st, c->b.pool_var,
                     c->b.pool_s64, c->b.rng_pix, c->b.rng_st, c->b.key, c->o.idx_local, c->o.idx_global, c->o.iso,
                     c->o.a, c->o.b, c->o.err, c->o.qrows};
     for (void* p : ptrs)
@@ -313,7 +316,9 @@ int fic_ctx_encode(fic_ctx* c, int range_begin, int range_count, void* hip_strea
     // sweep
     int kind = c->opt_sweep;
     if (kind == 0) kind = g.full ? 2 : 1;
-    if (kind == 2 && !g.full) return fail(FIC_E_ARGUMENT, "fast sweep needs full search (wK == Dw == Dh)");
+    if (kind >= 2 && !g.full) return fail(FIC_E_ARGUMENT, "fast sweep needs full search (wK == Dw == Dh)");
+    if (kind == 3 && !(g.B == 8 && g.n_iso == 8))
+        return fail(FIC_E_ARGUMENT, "the matrix-core sweep is built for B = 8, n_iso = 8 only");
     const int tsz = 64 * g.NR;
     const int tile0 = range_begin / tsz;
     const int tile1 = (range_begin + range_count + tsz - 1) / tsz;
@@ -330,6 +335,40 @@ int fic_ctx_encode(fic_ctx* c, int range_begin, int range_count, void* hip_strea
     int nchunks = 1;
     if (kind == 1) {
         if (fic_launch_sweep_generic(c->b, g, range_begin, range_count, s)) return fail(FIC_E_HIP, "k_sweep_generic launch failed");
+    } else if (kind == 3) {
+        const int ndtiles = (g.Nd + 31) / 32, ndtiles_alloc = ndtiles + 1;
+        const size_t P = (size_t)g.planes;
+        if (!c->mfma_poolB) {
+            HIP_TRY(hipMalloc(&c->mfma_poolB, P * ndtiles_alloc * 128 * 16));
+            HIP_TRY(hipMalloc(&c->mfma_rngA, P * g.tiles * FIC_MFMA_RT_HOST * 128 * 16));
+            HIP_TRY(hipMalloc((void**)&c->mfma_rconst, P * g.tiles * FIC_MFMA_RT_HOST * 16 * sizeof(int)));
+        }
+        // the fragment prep belongs to the pool build / range prep, not to the timed sweep
+        if (c->opt_time) { hipEventDestroy(e0); hipEventDestroy(e1); e0 = e1 = nullptr; }
+        if (fic_launch_mfma_prep_pool(c->b.pool_pix, c->mfma_poolB, g, ndtiles_alloc, s) ||
+            fic_launch_mfma_prep_range(c->b.rng_pix, c->b.rng_st, c->mfma_rngA, c->mfma_rconst, g, s))
+            return fail(FIC_E_HIP, "mfma prep launch failed");
+        if (c->opt_time) {
+            HIP_TRY(hipEventCreate(&e0));
+            HIP_TRY(hipEventCreate(&e1));
+            HIP_TRY(hipEventRecord(e0, s));
+        }
+        nchunks = c->opt_chunks;
+        if (nchunks <= 0) {
+            long long base_wg = (long long)ntiles * g.planes;        // workgroups per chunk (256 CUs x ~4 resident)
+            long long want = (4096 + base_wg - 1) / base_wg;
+            long long cap = ndtiles / 256;                            // >= 256 domain tiles per chunk: start-up cost < 10 %
+            if (cap < 1) cap = 1;
+            nchunks = (int)(want < cap ? want : cap);
+            if (nchunks < 1) nchunks = 1;
+        }
+        if (nchunks > ndtiles) nchunks = ndtiles;
+        int tiles_per_chunk = (ndtiles + nchunks - 1) / nchunks;
+        nchunks = (ndtiles + tiles_per_chunk - 1) / tiles_per_chunk;
+        if (nchunks > 65535) return fail(FIC_E_ARGUMENT, "too many chunks (%d)", nchunks);
+        if (fic_launch_sweep_mfma(c->b, c->mfma_poolB, c->mfma_rngA, c->mfma_rconst, g, tile0, ntiles, ndtiles, ndtiles_alloc,
+                                  tiles_per_chunk, nchunks, s))
+            return fail(FIC_E_HIP, "k_sweep_mfma launch failed");
     } else {
         int NR, NC;
         fic_fast_variant(g.B, g.n_iso, &NR, &NC);
@@ -419,7 +458,7 @@ int fic_ctx_set_option(fic_ctx* c, const char* name, int value)
 {
     if (!c || !name) return fail(FIC_E_ARGUMENT, "fic_ctx_set_option: null argument");
     if (!strcmp(name, "sweep")) {
-        if (value < 0 || value > 2) return fail(FIC_E_ARGUMENT, "sweep must be 0, 1 or 2");
+        if (value < 0 || value > 3) return fail(FIC_E_ARGUMENT, "sweep must be 0 (auto), 1 (generic), 2 (fast, VALU) or 3 (matrix-core)");
         c->opt_sweep = value;
     } else if (!strcmp(name, "chunks")) {
         if (value < 0) return fail(FIC_E_ARGUMENT, "chunks must be >= 0");

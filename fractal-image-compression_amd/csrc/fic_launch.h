@@ -71,6 +71,15 @@ struct FicRgbBuffers {
 int fic_launch_rgb_encode(const FicRgbBuffers& b, const FicRgbOutputs& out, int32_t* collage, const FicGeom& g,
                           hipStream_t s);
 
+// opt-in matrix-core sweep ("sweep" = 3)
+#define FIC_MFMA_RT_HOST 16
+int fic_launch_mfma_prep_pool(const uint8_t* pool_pix, void* poolB, const FicGeom& g, int ndtiles_alloc, hipStream_t s);
+int fic_launch_mfma_prep_range(const uint32_t* rng_pix, const FicRngStat* rng_st, void* rngA, int* rconst,
+                               const FicGeom& g, hipStream_t s);
+int fic_launch_sweep_mfma(const FicBuffers& b, const void* poolB, const void* rngA, const int* rconst, const FicGeom& g,
+                          int group0, int ngroups_launch, int ndtiles, int ndtiles_alloc, int tiles_per_chunk, int nchunks,
+                          hipStream_t s);
+
 // decoder (FC:356-421)
 int fic_launch_decode_iteration(uint8_t* scaled, uint8_t* image, const int32_t* qrows, const int32_t* iso,
                                 FicDecodeState* state, int counter, const FicGeom& g, hipStream_t s);

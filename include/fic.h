@@ -148,7 +148,8 @@ FIC_API int fic_decode_gray_run(const uint8_t* run, int64_t len, int device, uin
 FIC_API int fic_ctx_decode_host(fic_ctx* ctx, uint8_t* gray_out, float* avg_error_out, int* iterations_out);
 
 /* Tuning / instrumentation knobs:
- *   "sweep"       0 auto (fast kernel for full search, generic otherwise), 1 generic, 2 fast
+ *   "sweep"       0 auto (VALU fast kernel for full search, generic otherwise), 1 generic, 2 fast,
+ *                 3 = opt-in matrix-core sweep (B = 8, n_iso = 8, full search; same results)
  *   "chunks"      domain-pool chunks per range tile for the fast kernel (0 = auto)
  *   "time_sweep"  1: bracket every sweep launch with hipEvents on its stream */
 FIC_API int fic_ctx_set_option(fic_ctx* ctx, const char* name, int value);

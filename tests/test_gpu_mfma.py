@@ -1,0 +1,83 @@
+"""The opt-in matrix-core sweep ("sweep" = 3, B = 8, n_iso = 8) is held to the same bar as the default
+VALU sweep: bit-identical codebooks against the oracle, and against k_sweep_fast at sizes the oracle
+cannot reach."""
+import os
+
+import numpy as np
+import pytest
+
+import fic_amd
+from fic_amd import synth
+from conftest import GOLDEN, same_f32
+
+pytestmark = pytest.mark.gpu
+
+IMAGES = {
+    "lena64": np.load(os.path.join(GOLDEN, "lena64.npy")),
+    "lena256": np.load(os.path.join(GOLDEN, "lena_grey_256.npy")),
+    "U128": synth.image_u(128, 128, synth.SEEDS["cfg2"]),
+    "S128": synth.image_s(128, 128, synth.SEEDS["cfg2"]),
+    "S256": synth.image_s(256, 256, synth.SEEDS["cfg3"]),
+    "U256": synth.image_u(256, 256, synth.SEEDS["cfg3"]),
+    "flat64": np.full((64, 64), 77, np.uint8),
+    "U200": synth.image_u(200, 200, 11),     # N_r = 625: partial range group, N_d = 2209: partial domain tile
+    "S200": synth.image_s(200, 200, 12),
+}
+
+
+def _same(a, b):
+    for k in ("idx_local", "iso", "qrows", "idx_global"):
+        assert (a[k] == b[k]).all(), k
+    for k in ("a", "b", "err"):
+        assert same_f32(a[k], b[k]), k
+
+
+@pytest.mark.parametrize("name", sorted(IMAGES))
+@pytest.mark.parametrize("chunks", [0, 1, 3])
+def test_mfma_sweep_matches_oracle(oracle, name, chunks):
+    g = IMAGES[name]
+    h, w = g.shape
+    Dw = fic_amd.geometry(w, h, 8)[2]
+    ref = oracle.encode_gray(oracle.gray_to_argb(g), w, h, 8, Dw, 8)
+    got = fic_amd.encode_gray(g, 8, None, 8, sweep=3, chunks=chunks)
+    assert (got["idx_local"] == ref["info"][:, 0].astype(np.int32)).all()
+    assert (got["iso"] == ref["iso"]).all()
+    assert same_f32(got["a"], ref["info"][:, 1]) and same_f32(got["b"], ref["info"][:, 2])
+    assert (got["qrows"] == oracle.quantise_gray(ref["info"])).all()
+    assert same_f32(got["err"], ref["err"])
+
+
+def test_mfma_equals_valu_sweep_at_cfg2_size_and_batched():
+    imgs = np.stack([synth.image_u(512, 512, synth.SEEDS["cfg2"]), synth.image_s(512, 512, 99),
+                     synth.image_u(512, 512, 5)])
+    res = {}
+    for sweep in (2, 3):
+        with fic_amd.Encoder(512, 512, 8, None, 8, planes=3) as enc:
+            enc.set_option("sweep", sweep)
+            enc.set_gray(imgs)
+            enc.encode()
+            res[sweep] = enc.results()
+            assert enc.info()["sweep_kind"] == sweep
+    _same(res[2], res[3])
+
+
+def test_mfma_shards_and_1024():
+    g = synth.image_u(1024, 1024, 21)
+    whole = fic_amd.encode_gray(g, 8, None, 8, sweep=2)
+    with fic_amd.Encoder(1024, 1024, 8, None, 8) as enc:
+        enc.set_option("sweep", 3)
+        enc.set_gray(g)
+        parts = []
+        for b, c in fic_amd.shard_spans(enc.n_ranges, enc.ranges_per_tile, 3):
+            enc.encode(b, c)
+            r = enc.results()
+            parts.append({k: v[0][b:b + c].copy() for k, v in r.items()})
+    cat = {k: np.concatenate([p[k] for p in parts]) for k in parts[0]}
+    _same(cat, whole)
+
+
+def test_mfma_is_refused_outside_its_configuration():
+    with pytest.raises(fic_amd.FicError):
+        fic_amd.encode_gray(IMAGES["lena256"], 8, None, 1, sweep=3)
+    with pytest.raises(fic_amd.FicError):
+        fic_amd.encode_gray(IMAGES["lena256"], 16, None, 8, sweep=3)
