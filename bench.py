@@ -87,6 +87,7 @@ def main():
     ap.add_argument("--sweep", type=int, default=0, choices=[0, 2, 3],
                     help="0/2 = VALU sweep k_sweep_fast (default, north_star's design); 3 = opt-in matrix-core sweep")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-alt", action="store_true", help="skip the extra timing of the opt-in matrix-core sweep")
     ap.add_argument("--cpu-budget", type=float, default=12.0)
     args = ap.parse_args()
 
@@ -227,6 +228,26 @@ def main():
             out["valu"] = {"bound": "valu-issue (epilogue)", "valu_instr_per_pair_eval": vpe,
                            "frac": pair_evals * vpe / 64.0 / (avg_ms * 1e-3) / VALU_WAVE_INSTR_PEAK,
                            "peak_wave_instr_per_s": VALU_WAVE_INSTR_PEAK}
+        if info["sweep_kind"] == 2 and B == 8 and n_iso == 8 and world == 1 and not args.no_alt:
+            # Same workload, same buffers, through the opt-in matrix-core sweep: reported beside, never as `value`.
+            core.set_option("sweep", 3)
+            for _ in range(args.warmup):
+                step()
+            torch.cuda.synchronize()
+            core.sweep_time(reset=True)
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                step()
+            torch.cuda.synchronize()
+            dt3 = time.perf_counter() - t1
+            ms3, n3 = core.sweep_time(reset=True)
+            core.set_option("sweep", 0)
+            out["opt_in_matrix_core"] = {
+                "how": "bench.py --sweep 3 / fic_ctx_set_option(ctx, \"sweep\", 3)", "kernel": "k_sweep_mfma",
+                "value": total_ranges / dt3, "unit": "range-block matches/s", "ms_per_step": dt3 / args.steps * 1e3,
+                "avg_launch_ms": ms3 / max(n3, 1), "speedup_vs_default": dt / dt3,
+                "note": "bit-identical codebooks (tests/test_gpu_mfma.py); inner products on v_mfma_i32_32x32x32_i8. "
+                        "Not the default because north_star asks for a VALU-only sweep (DESIGN.md section 6)."}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(wl, imgs[0], args.cpu_budget)
         else:

@@ -120,6 +120,26 @@ def decode_gray_run(run, device=0, avg_error_in=0.0):
     return out[:cap].reshape(h, w), np.float32(avg.value), it.value
 
 
+def decode_rgb_run(run, device=0, avg_error_in=0.0):
+    """decodeRGB (FC:430-508) on the GPU.  Returns (argb int32 [H*W], avgError float32, iterations, w, h)."""
+    L = lib()
+    L.fic_decode_rgb_run.restype = C.c_int
+    L.fic_decode_rgb_run.argtypes = [C.POINTER(C.c_uint8), C.c_int64, C.c_int, C.POINTER(C.c_int32), C.c_int64,
+                                     C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_float), C.POINTER(C.c_int)]
+    buf = np.frombuffer(bytes(run), np.uint8)
+    if buf.size < 20:
+        raise FicError(-3, "run stream shorter than its header")
+    w = int.from_bytes(bytes(run[4:8]), "big", signed=True)
+    h = int.from_bytes(bytes(run[8:12]), "big", signed=True)
+    cap = max(w, 0) * max(h, 0)
+    out = np.zeros(max(cap, 1), np.int32)
+    avg = C.c_float(avg_error_in)
+    it, wo, ho = C.c_int(), C.c_int(), C.c_int()
+    check(L.fic_decode_rgb_run(ptr(buf, C.c_uint8), buf.size, device, ptr(out, C.c_int32), cap, C.byref(wo), C.byref(ho),
+                               C.byref(avg), C.byref(it)))
+    return out[:cap], np.float32(avg.value), it.value, w, h
+
+
 def encode_rgb(argb, w, h, B, wK, device=0, want_collage=False):
     """encodeRGB (FC:171-219) on the GPU.  argb: int32 [h*w].  Returns a dict of [N_r] arrays
     (idx_local, a, bR, bG, bB, qrows [N_r,5]) and, when asked, the collage (int32 [h*w])."""

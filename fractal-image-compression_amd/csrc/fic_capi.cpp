@@ -638,6 +638,71 @@ int fic_decode_gray_run(const uint8_t* run, int64_t len, int device, uint8_t* gr
     return rc;
 }
 
+// ---- decodeRGB (FC:430-508) -----------------------------------------------------------------------
+int fic_decode_rgb_run(const uint8_t* run, int64_t len, int device, int32_t* argb_out, int64_t capacity_pixels,
+                       int* w_out, int* h_out, float* avg_error_io, int* iterations)
+{
+    if (!run || len < 20) return fail(FIC_E_ARGUMENT, "fic_decode_rgb_run: stream shorter than the 20-byte header");
+    auto be = [&](int64_t off) {
+        return (int32_t)(((uint32_t)run[off] << 24) | ((uint32_t)run[off + 1] << 16) | ((uint32_t)run[off + 2] << 8) |
+                         (uint32_t)run[off + 3]);
+    };
+    if (be(0) == 0) return fail(FIC_E_ARGUMENT, "fic_decode_rgb_run: isRGB = 0 (FC:548-550 dispatches to decodeGreyScale)");
+    const int w = be(4), h = be(8), B = be(12), wK = be(16);
+    FicGeom g;
+    int rc = make_geometry(w, h, B, wK, 1, 1, &g);
+    if (rc) return rc;
+    if (w_out) *w_out = w;
+    if (h_out) *h_out = h;
+    if (len < 20 + 20 * (int64_t)g.Nr)
+        return fail(FIC_E_ARGUMENT, "fic_decode_rgb_run: %lld bytes, need %lld (EOFException in the reference)",
+                    (long long)len, (long long)(20 + 20 * (int64_t)g.Nr));
+    if (!argb_out || capacity_pixels < (int64_t)w * h) return fail(FIC_E_CAPACITY, "fic_decode_rgb_run: output needs %d ints", w * h);
+    int ndev = fic_device_count();
+    if (ndev <= 0 || device < 0 || device >= ndev) return fail(FIC_E_NO_DEVICE, "no HIP device %d (this library has no CPU path)", device);
+    HIP_TRY(hipSetDevice(device));
+    std::vector<int32_t> q((size_t)g.Nr * 5);
+    for (size_t i = 0; i < q.size(); i++) q[i] = be(20 + 4 * (int64_t)i);          // FC:446-450
+    const size_t npix = (size_t)w * h;
+    std::vector<int32_t> init(npix, (int32_t)0xff808080u);                          // generateGrayImage FC:1142-1148
+    int32_t *d_scaled = nullptr, *d_image = nullptr, *d_q = nullptr;
+    FicDecodeState* d_state = nullptr;
+    FicDecodeState st;
+    memset(&st, 0, sizeof(st));
+    st.avg = avg_error_io ? *avg_error_io : 0.0f;
+    hipError_t e = hipMalloc((void**)&d_scaled, (size_t)g.Ws * g.Hs * 4);
+    if (e == hipSuccess) e = hipMalloc((void**)&d_image, npix * 4);
+    if (e == hipSuccess) e = hipMalloc((void**)&d_q, q.size() * 4);
+    if (e == hipSuccess) e = hipMalloc((void**)&d_state, sizeof(st));
+    if (e == hipSuccess) e = hipMemcpy(d_q, q.data(), q.size() * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_image, init.data(), npix * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_state, &st, sizeof(st), hipMemcpyHostToDevice);
+    if (e != hipSuccess) rc = fail(FIC_E_HIP, "fic_decode_rgb_run: %s", hipGetErrorString(e));
+    for (int counter = 0; rc == FIC_OK && counter < 50; counter++) {
+        if (fic_launch_decode_iteration_rgb(d_scaled, d_image, d_q, d_state, counter, g, nullptr)) {
+            rc = fail(FIC_E_HIP, "decodeRGB iteration launch failed");
+            break;
+        }
+        if ((counter & 7) == 7 || counter == 49) {
+            e = hipMemcpy(&st, d_state, sizeof(st), hipMemcpyDeviceToHost);
+            if (e != hipSuccess) { rc = fail(FIC_E_HIP, "decodeRGB readback: %s", hipGetErrorString(e)); break; }
+            if (st.done) break;
+        }
+    }
+    if (rc == FIC_OK && st.bad_index)
+        rc = fail(FIC_E_ARGUMENT, "decodeRGB: a codebook row points outside the domain pool (ArrayIndexOutOfBounds at FC:477)");
+    if (rc == FIC_OK) {
+        e = hipMemcpy(argb_out, d_image, npix * 4, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = fail(FIC_E_HIP, "fic_decode_rgb_run: %s", hipGetErrorString(e));
+    }
+    if (rc == FIC_OK) {
+        if (avg_error_io) *avg_error_io = st.avg_out;
+        if (iterations) *iterations = st.iters;
+    }
+    hipFree(d_scaled); hipFree(d_image); hipFree(d_q); hipFree(d_state);
+    return rc;
+}
+
 // ---- joint-RGB encode (encodeRGB FC:171-219) -----------------------------------------------------
 int fic_encode_rgb_argb(const int32_t* argb, int w, int h, int B, int wK, int device, int32_t* idx_local, float* a,
                         float* bR, float* bG, float* bB, int32_t* qrows5, int32_t* collage_argb)

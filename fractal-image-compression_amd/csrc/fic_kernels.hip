@@ -233,45 +233,57 @@ __global__ __launch_bounds__(256) void k_pool(const uint8_t* __restrict__ scaled
 // One thread per range block.  copy_k[pos] = r[iso_source(inverse(k), pos)] so that
 //   dot(copy_k, d) == dot(r, iso_k(d)).
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_range(const uint8_t* __restrict__ gray, uint32_t* __restrict__ rng_pix,
-                                               FicRngStat* __restrict__ rng_st, FicGeom g)
+// (a) statistics: one thread per range block, rows read as 4-byte words, byte sums with v_sad_u8
+__global__ __launch_bounds__(256) void k_range_stat(const uint8_t* __restrict__ gray, FicRngStat* __restrict__ rng_st, FicGeom g)
 {
     int j = blockIdx.x * 256 + threadIdx.x;
     int plane = blockIdx.y;
     if (j >= g.Nr_pad) return;
-    uint32_t* out = rng_pix + (size_t)plane * g.Nr_pad * g.n_iso * g.DW;
     FicRngStat st;
     st.rM = 0;
     st.rem = 0;
-    if (j >= g.Nr) {     // tile padding: zero pixels, never written back
-        for (int k = 0; k < g.n_iso; k++)
-            for (int dw = 0; dw < g.DW; dw++) out[rng_word_index(g, j, k, dw)] = 0;
-        rng_st[(size_t)plane * g.Nr_pad + j] = st;
-        return;
+    if (j < g.Nr) {
+        const int B = g.B;
+        const uint8_t* im = gray + (size_t)plane * g.W * g.H + (size_t)((j / g.Rw) * B) * g.W + (j % g.Rw) * B;
+        uint32_t S = 0;
+        for (int y = 0; y < B; y++) {
+            const uint32_t* row = (const uint32_t*)(im + (size_t)y * g.W);      // B is a multiple of 4, W of B
+            for (int x = 0; x < B / 4; x++) S = __builtin_amdgcn_sad_u8(row[x], 0u, S);
+        }
+        st.rM = (int)(S >> g.lgn);
+        st.rem = (int)S - (st.rM << g.lgn);
     }
-    const int B = g.B;
-    int x0 = (j % g.Rw) * B, y0 = (j / g.Rw) * B;
-    const uint8_t* im = gray + (size_t)plane * g.W * g.H + (size_t)y0 * g.W + x0;
-    int S = 0;
-    for (int y = 0; y < B; y++)
-        for (int x = 0; x < B; x++) S += im[(size_t)y * g.W + x];
-    st.rM = S >> g.lgn;
-    st.rem = S - (st.rM << g.lgn);
     rng_st[(size_t)plane * g.Nr_pad + j] = st;
-    for (int k = 0; k < g.n_iso; k++) {
-        int ki = iso_inverse(k);
-        for (int dw = 0; dw < g.DW; dw++) {
-            uint32_t w = 0;
+}
+
+// (b) pixels: one thread per output dword (range j, isometry copy k, dword dw); consecutive threads are
+// consecutive lanes of the lane-transposed store, so every wave writes one coalesced 256-byte run.
+__global__ __launch_bounds__(256) void k_range_copies(const uint8_t* __restrict__ gray, uint32_t* __restrict__ rng_pix, FicGeom g)
+{
+    const int plane = blockIdx.y;
+    const size_t per_plane = (size_t)g.Nr_pad * g.n_iso * g.DW;
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;        // index into rng_pix[plane]: [tile][rs][k][dw][lane]
+    if (i >= per_plane) return;
+    const int lane = (int)(i & 63);
+    size_t r = i >> 6;
+    const int dw = (int)(r % g.DW); r /= g.DW;
+    const int k = (int)(r % g.n_iso); r /= g.n_iso;
+    const int rs = (int)(r % g.NR);
+    const int tile = (int)(r / g.NR);
+    const int j = (tile * g.NR + rs) * 64 + lane;
+    uint32_t w = 0;
+    if (j < g.Nr) {                                           // tile padding stays zero (never written back)
+        const int B = g.B;
+        const uint8_t* im = gray + (size_t)plane * g.W * g.H + (size_t)((j / g.Rw) * B) * g.W + (j % g.Rw) * B;
+        const int ki = iso_inverse(k);
 #pragma unroll
-            for (int t = 0; t < 4; t++) {
-                int pos = dw * 4 + t;
-                int src = iso_source(ki, B, pos % B, pos / B);
-                uint32_t v = im[(size_t)(src / B) * g.W + (src % B)];
-                w |= v << (8 * t);
-            }
-            out[rng_word_index(g, j, k, dw)] = w;
+        for (int t = 0; t < 4; t++) {
+            const int pos = dw * 4 + t;
+            const int src = iso_source(ki, B, pos % B, pos / B);
+            w |= (uint32_t)im[(size_t)(src / B) * g.W + (src % B)] << (8 * t);
         }
     }
+    rng_pix[(size_t)plane * per_plane + i] = w;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -674,6 +686,7 @@ __global__ __launch_bounds__(256) void k_sweep_mfma(MfmaArgs A)
             // Per range q: cov_e = acc[e] + Kq + Aq*sum(d) - rem*dM (exact, 24-bit operands); the pair needs the
             // exact epilogue iff |cov_e| > li = floor(tau*s32)  <=>  (unsigned)(cov_e + li) > 2*li.
             uint32_t offq[4], spanq[4];
+            bool anyq[4];
             bool any = false;
 #pragma unroll
             for (int q = 0; q < 4; q++) {
@@ -688,15 +701,17 @@ __global__ __launch_bounds__(256) void k_sweep_mfma(MfmaArgs A)
                 const uint32_t u0 = (uint32_t)acc[4 * q + 0] + offq[q], u1 = (uint32_t)acc[4 * q + 1] + offq[q];
                 const uint32_t u2 = (uint32_t)acc[4 * q + 2] + offq[q], u3 = (uint32_t)acc[4 * q + 3] + offq[q];
                 const uint32_t m01 = u0 > u1 ? u0 : u1, m23 = u2 > u3 ? u2 : u3;
-                any |= (m01 > m23 ? m01 : m23) > spanq[q];
+                anyq[q] = (m01 > m23 ? m01 : m23) > spanq[q];
+                any |= anyq[q];
             }
             if (__builtin_expect(__any(any || force), 0)) {
                 const double s64 = valid ? p64[d] : 0.0;
 #pragma unroll
                 for (int e = 0; e < 16; e++) {
                     const int q = e >> 2;
+                    if (!((anyq[q] || force) && valid)) continue;       // whole range untouched on this lane: skip its 4 copies
                     const uint32_t u = (uint32_t)acc[e] + offq[q];
-                    if ((u > spanq[q] || force) && valid) {
+                    if (u > spanq[q] || force) {
                         const int cov = (int)(u - (spanq[q] >> 1));
                         const int rem = -rc[8 + q];
                         const float err = exact_error(cov, rem, s64);
@@ -1043,6 +1058,54 @@ __global__ __launch_bounds__(256) void k_collage_rgb(const int32_t* __restrict__
     collage[(size_t)y * g.W + x] = (int32_t)(0xff000000u | ((uint32_t)vR << 16) | ((uint32_t)vG << 8) | (uint32_t)vB);
 }
 
+// decodeRGB paint FC:463-499: a = q1/1000000f, bR = q2/100000f, bG = q3/100000f, bB = (float)q4 (FC:446-450);
+// the squared change of the three channels is summed as an int per pixel before the float add (FC:493).
+__global__ __launch_bounds__(256) void k_decode_paint_rgb(const int32_t* __restrict__ scaled, int32_t* __restrict__ image,
+                                                          const int32_t* __restrict__ qrows5,
+                                                          FicDecodeState* __restrict__ st, int counter, FicGeom g)
+{
+    int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (st->done) return;
+    unsigned long long sq = 0;
+    if (x < g.W) {
+        int j = (y / g.B) * g.Rw + (x / g.B);
+        int rx = x % g.B, ry = y % g.B;
+        int wloc = qrows5[5 * j + 0];
+        float a = __fdiv_rn((float)qrows5[5 * j + 1], 1000000.0f);
+        float bR = __fdiv_rn((float)qrows5[5 * j + 2], 100000.0f);
+        float bG = __fdiv_rn((float)qrows5[5 * j + 3], 100000.0f);
+        float bB = (float)qrows5[5 * j + 4];
+        bool ok = wloc >= 0 && wloc < g.wK * g.wK;
+        int gi = ok ? window_to_global(g, j, wloc) : 0;
+        if (!ok || gi < 0 || gi >= g.Nd) {
+            st->bad_index = 1;
+        } else {
+            int c = gi % g.Dw, r = gi / g.Dw;
+            int32_t d = scaled[(size_t)(r * g.abstand + ry) * g.Ws + c * g.abstand + rx];
+            int vR = java_f2i(__fadd_rn(__fmul_rn(a, (float)ch_r(d)), bR));
+            int vG = java_f2i(__fadd_rn(__fmul_rn(a, (float)ch_g(d)), bG));
+            int vB = java_f2i(__fadd_rn(__fmul_rn(a, (float)ch_b(d)), bB));
+            vR = vR < 0 ? 0 : (vR > 255 ? 255 : vR);
+            vG = vG < 0 ? 0 : (vG > 255 ? 255 : vG);
+            vB = vB < 0 ? 0 : (vB > 255 ? 255 : vB);
+            size_t p = (size_t)y * g.W + x;
+            int32_t cur = image[p];
+            int dR = ch_r(cur) - vR, dG = ch_g(cur) - vG, dB = ch_b(cur) - vB;
+            image[p] = (int32_t)(0xff000000u | ((uint32_t)vR << 16) | ((uint32_t)vG << 8) | (uint32_t)vB);
+            sq = (unsigned long long)(dR * dR + dG * dG + dB * dB);
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) sq += __shfl_xor(sq, off, 64);
+    __shared__ unsigned long long s_part[4];
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = sq;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long t = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+        if (t) atomicAdd(&st->ssd[counter], t);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // k_sqrt_probe : test hook -- out[i] = sqrt((double)(first + i)) as the pool kernel computes it,
 // so the test-suite can compare every possible variance value (0 .. 2^24) with the host's sqrt.
@@ -1089,7 +1152,10 @@ int fic_launch_pool(const uint8_t* scaled, uint8_t* pool_pix, FicDomStat* st, ui
 
 int fic_launch_range(const uint8_t* gray, uint32_t* rng_pix, FicRngStat* rst, const FicGeom& g, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_range, dim3((g.Nr_pad + 255) / 256, g.planes), dim3(256), 0, s, gray, rng_pix, rst, g);
+    hipLaunchKernelGGL(k_range_stat, dim3((g.Nr_pad + 255) / 256, g.planes), dim3(256), 0, s, gray, rst, g);
+    FIC_LAUNCH_CHECK();
+    size_t per_plane = (size_t)g.Nr_pad * g.n_iso * g.DW;
+    hipLaunchKernelGGL(k_range_copies, dim3((unsigned)((per_plane + 255) / 256), g.planes), dim3(256), 0, s, gray, rng_pix, g);
     FIC_LAUNCH_CHECK();
     return 0;
 }
@@ -1224,6 +1290,20 @@ int fic_launch_rgb_encode(const FicRgbBuffers& b, const FicRgbOutputs& out, int3
                            collage, g);
         FIC_LAUNCH_CHECK();
     }
+    return 0;
+}
+
+// one decodeRGB iteration (FC:458-505): scaleImageRGB of the current image, paint, loop control
+int fic_launch_decode_iteration_rgb(int32_t* scaled, int32_t* image, const int32_t* qrows5, FicDecodeState* state,
+                                    int counter, const FicGeom& g, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_scale_rgb, dim3((g.Ws + 255) / 256, g.Hs), dim3(256), 0, s, (const int32_t*)image, scaled, g);
+    FIC_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_decode_paint_rgb, dim3((g.W + 255) / 256, g.H), dim3(256), 0, s, (const int32_t*)scaled, image,
+                       qrows5, state, counter, g);
+    FIC_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_decode_step, dim3(1), dim3(64), 0, s, state, counter, g.W * g.H, 1);
+    FIC_LAUNCH_CHECK();
     return 0;
 }
 

@@ -80,6 +80,9 @@ int fic_launch_sweep_mfma(const FicBuffers& b, const void* poolB, const void* rn
                           int group0, int ngroups_launch, int ndtiles, int ndtiles_alloc, int tiles_per_chunk, int nchunks,
                           hipStream_t s);
 
+int fic_launch_decode_iteration_rgb(int32_t* scaled, int32_t* image, const int32_t* qrows5, FicDecodeState* state,
+                                    int counter, const FicGeom& g, hipStream_t s);
+
 // decoder (FC:356-421)
 int fic_launch_decode_iteration(uint8_t* scaled, uint8_t* image, const int32_t* qrows, const int32_t* iso,
                                 FicDecodeState* state, int counter, const FicGeom& g, hipStream_t s);

@@ -241,8 +241,10 @@ class FractalCompression:
     @classmethod
     def decode(cls, inputStream):   # FC:547-553
         data = inputStream.read() if hasattr(inputStream, "read") else bytes(inputStream)
-        if len(data) >= 4 and int.from_bytes(data[:4], "big", signed=True) != 0:
-            raise NotImplementedError("decodeRGB (FC:430-508) is not GPU-backed yet")
+        if len(data) >= 4 and int.from_bytes(data[:4], "big", signed=True) != 0:      # FC:549-552 -> decodeRGB
+            argb, avg, _, w, h = capi.decode_rgb_run(data, cls.device, float(cls.avgError))
+            cls.avgError = avg
+            return RasterImage(w, h, argb)
         gray, avg, _ = capi.decode_gray_run(data, cls.device, float(cls.avgError))
         cls.avgError = avg
         return RasterImage.from_gray(gray)

@@ -142,6 +142,11 @@ FIC_API int64_t fic_write_run_rgb(const int32_t* qrows5, int n_ranges, int w, in
  * whenever it is below 2^24, which holds for the iteration that ends a converging decode. */
 FIC_API int fic_decode_gray_run(const uint8_t* run, int64_t len, int device, uint8_t* gray_out, int64_t capacity,
                                 int* w, int* h, float* avg_error_io, int* iterations);
+/* decodeRGB (FractalCompression.java:430-508) on a complete colour .run stream (isRGB != 0):
+ * rows {idx, a*1e6, bR*1e5, bG*1e5, bB} (:446-450), scaleImageRGB pool, per-channel repaint, the
+ * three squared channel changes summed per pixel (:493).  argb_out: w*h ARGB ints. */
+FIC_API int fic_decode_rgb_run(const uint8_t* run, int64_t len, int device, int32_t* argb_out,
+                               int64_t capacity_pixels, int* w, int* h, float* avg_error_io, int* iterations);
 /* The same loop driven from the context's last encode: quantised rows (and isometry ids, so
  * n_iso = 8 codebooks decode too) stay on the device.  gray_out [planes][h][w]; avg_error_out and
  * iterations_out [planes], may be NULL.  Every range block must have been encoded. */

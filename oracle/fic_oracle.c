@@ -853,6 +853,75 @@ FO_API int fo_collage_rgb(const int32_t* argb, int w, int h, int B, int wK, floa
     return 0;
 }
 
+/* decodeRGB FC:430-508.  run = full stream including the leading isRGB int.  out_argb: w*h ints. */
+FO_API int fo_decode_rgb(const uint8_t* run, int64_t len, int32_t* out_argb, int out_capacity, float* avg_error_io,
+                         int* iters_out, int* w_out, int* h_out)
+{
+    if (len < 20) return -20;
+    if (get_be32(run) == 0) return -21;
+    int width = get_be32(run + 4), height = get_be32(run + 8);
+    int B = get_be32(run + 12), wK = get_be32(run + 16);
+    int Rw, Rh, Dw, Dh;
+    int rc = fo_geometry(width, height, B, &Rw, &Rh, &Dw, &Dh);
+    if (rc) return rc;
+    if (w_out) *w_out = width;
+    if (h_out) *h_out = height;
+    if ((int64_t)width * height > out_capacity) return -22;
+    int nr = Rw * Rh, n = B * B;
+    if (len < 20 + 20 * (int64_t)nr) return -23;
+    for (int i = 0; i < width * height; i++) out_argb[i] = grey_argb(128);
+    float* imgData = (float*)malloc(sizeof(float) * 5 * (size_t)nr);
+    const uint8_t* p = run + 20;
+    for (int rows = 0; rows < nr; rows++) {
+        imgData[5 * rows + 0] = (float)get_be32(p);
+        imgData[5 * rows + 1] = (float)get_be32(p + 4) / 1000000.0f;
+        imgData[5 * rows + 2] = (float)get_be32(p + 8) / 100000.0f;
+        imgData[5 * rows + 3] = (float)get_be32(p + 12) / 100000.0f;
+        imgData[5 * rows + 4] = (float)get_be32(p + 16);
+        p += 20;
+    }
+    fo_calculate_indices(imgData, 5, width, height, B, wK);
+    float avgError = avg_error_io ? *avg_error_io : 0.0f;
+    int iters = 0;
+    for (int counter = 0; counter < 50; counter++) {
+        fo_codebook_rgb cb;
+        rc = fo_create_codebuch_rgb(out_argb, width, height, B, &cb);
+        if (rc) { fo_codebook_rgb_free(&cb); free(imgData); return rc; }
+        int i = 0;
+        for (int y = 0; y < height; y += B)
+            for (int x = 0; x < width; x += B) {
+                int g = fo_java_f2i(imgData[5 * i + 0]);
+                if (g < 0 || g >= cb.count) { fo_codebook_rgb_free(&cb); free(imgData); return -24; }
+                for (int ry = 0; ry < B && y + ry < height; ry++)
+                    for (int rx = 0; rx < B && x + rx < width; rx++) {
+                        int32_t cur = out_argb[x + rx + (y + ry) * width];
+                        int rangeR = red(cur), rangeG = green(cur), rangeB = blue(cur);
+                        int32_t d = cb.argb[(size_t)g * n + rx + ry * B];
+                        int vR = fo_java_f2i(imgData[5 * i + 1] * (float)red(d) + imgData[5 * i + 2]);
+                        int vG = fo_java_f2i(imgData[5 * i + 1] * (float)green(d) + imgData[5 * i + 3]);
+                        int vB = fo_java_f2i(imgData[5 * i + 1] * (float)blue(d) + imgData[5 * i + 4]);
+                        vR = vR < 0 ? 0 : (vR > 255 ? 255 : vR);
+                        vG = vG < 0 ? 0 : (vG > 255 ? 255 : vG);
+                        vB = vB < 0 ? 0 : (vB > 255 ? 255 : vB);
+                        out_argb[x + rx + (y + ry) * width] =
+                            (int32_t)(0xff000000u | ((uint32_t)vR << 16) | ((uint32_t)vG << 8) | (uint32_t)vB);
+                        avgError += (float)((rangeR - vR) * (rangeR - vR) + (rangeG - vG) * (rangeG - vG) +
+                                            (rangeB - vB) * (rangeB - vB));
+                    }
+                i++;
+            }
+        fo_codebook_rgb_free(&cb);
+        iters = counter + 1;
+        avgError = avgError / (float)(width * height);
+        if (avgError < 1) break;
+        if (counter != 49) avgError = 0;
+    }
+    free(imgData);
+    if (avg_error_io) *avg_error_io = avgError;
+    if (iters_out) *iters_out = iters;
+    return 0;
+}
+
 /* writeData, RGB branch FC:248-257 */
 FO_API int64_t fo_write_run_rgb(const float* info, int n_ranges, int w, int h, int B, int wK, uint8_t* out)
 {

@@ -187,6 +187,26 @@ def encode_rgb(argb, w, h, B, wK):
     return info
 
 
+def decode_rgb(run, avg_error_in=0.0):
+    """decodeRGB (FC:430-508).  Returns (rgb uint8 [H,W,3], avgError float32, iterations)."""
+    L = lib()
+    L.fo_decode_rgb.argtypes = [C.POINTER(C.c_uint8), C.c_int64, C.POINTER(C.c_int32), C.c_int, C.POINTER(C.c_float),
+                                C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    buf = np.frombuffer(run, np.uint8).copy()
+    w = int.from_bytes(run[4:8], "big", signed=True)
+    h = int.from_bytes(run[8:12], "big", signed=True)
+    out = np.zeros(w * h, np.int32)
+    avg = C.c_float(avg_error_in)
+    iters, wo, ho = C.c_int(), C.c_int(), C.c_int()
+    rc = L.fo_decode_rgb(_p(buf, C.c_uint8), buf.size, _p(out, C.c_int32), out.size, C.byref(avg), C.byref(iters),
+                         C.byref(wo), C.byref(ho))
+    if rc:
+        raise ValueError(f"fo_decode_rgb rc={rc}")
+    u = out.view(np.uint32)
+    rgb = np.stack([(u >> 16) & 0xFF, (u >> 8) & 0xFF, u & 0xFF], axis=-1).astype(np.uint8).reshape(h, w, 3)
+    return rgb, np.float32(avg.value), iters.value
+
+
 def collage_rgb(argb, w, h, B, wK, info):
     L = lib()
     L.fo_collage_rgb.argtypes = [C.POINTER(C.c_int32), C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float),

@@ -86,3 +86,30 @@ def test_rgb_errors():
     assert e.value.code == -2
     with pytest.raises(fic_amd.FicError):
         fic_amd.encode_rgb(argb, 64, 62, 8, 2)
+
+
+@pytest.mark.parametrize("B,wK", [(8, 2), (8, 16), (4, 4), (16, 8), (8, 61)])
+def test_decode_rgb_matches_reference_decoder(lena_colored, oracle, B, wK):
+    """decodeRGB (FC:430-508) on the GPU vs the oracle: image, avgError bits, iterations."""
+    argb = oracle.rgb_to_argb(lena_colored)
+    run = oracle.write_run_rgb(oracle.encode_rgb(argb, 256, 256, B, wK), 256, 256, B, wK)
+    want, wavg, wit = oracle.decode_rgb(run)
+    got, avg, it, w, h = fic_amd.decode_rgb_run(run)
+    u = got.view(np.uint32)
+    rgb = np.stack([(u >> 16) & 0xFF, (u >> 8) & 0xFF, u & 0xFF], axis=-1).astype(np.uint8).reshape(h, w, 3)
+    assert (w, h) == (256, 256) and it == wit
+    assert (rgb == want).all()
+    assert np.float32(avg).view(np.uint32) == np.float32(wavg).view(np.uint32)
+
+
+def test_k1_stream_decodes_through_the_mirror(oracle):
+    """FractalCompression.decode(stream) on the reference's own unknown.run (isRGB = 1, FC:547-553)."""
+    run = open(os.path.join(GOLDEN, "unknown_run.bin"), "rb").read()
+    fc = fic_amd.FractalCompression
+    fc.avgError = np.float32(0.0)
+    img = fc.decode(io.BytesIO(run))
+    want, wavg, _ = oracle.decode_rgb(run)
+    u = img.argb.view(np.uint32)
+    rgb = np.stack([(u >> 16) & 0xFF, (u >> 8) & 0xFF, u & 0xFF], axis=-1).astype(np.uint8).reshape(256, 256, 3)
+    assert (rgb == want).all() and fc.getAvgError() == wavg
+    assert (img.argb.view(np.uint32) >> 24 == 0xFF).all()
