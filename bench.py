@@ -109,12 +109,19 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: the hot path has no CPU fallback")
+    # FIC_BENCH_BACKEND=gloo is a rehearsal mode for boxes with fewer GPUs than ranks (ranks share devices,
+    # records travel through host memory); the real multi-GPU run uses nccl == RCCL over xGMI.
+    backend = os.environ.get("FIC_BENCH_BACKEND", "nccl")
+    local_rank = local_rank % torch.cuda.device_count() if backend == "gloo" else local_rank
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     W, H, B, n_iso, planes = wl["W"], wl["H"], wl["B"], wl["n_iso"], wl["planes"]
     seed = fic_amd.synth.SEEDS[wl["seed"]]
@@ -146,6 +153,8 @@ def main():
         core.encode(begin, count, stream)
         if world > 1:
             rec = fic_amd.pack_records(res_dev, begin, count)
+            if backend != "nccl":
+                rec = rec.cpu()
             if scaling == "strong":
                 fic_amd.gather_records(rec, enc.spans, None, 0)
             else:
@@ -168,7 +177,7 @@ def main():
     dt = time.perf_counter() - t0
     sweep_ms, sweep_n = core.sweep_time(reset=True)
     if dist:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -190,6 +199,14 @@ def main():
         # n/4 v_dot4 + cvt + cmp per isometry copy, + 3 per (range,domain) shared by the copies
         valu_per_eval = n / 4 + 2 + 3.0 / (n_iso if n_iso > 1 else 1)
         valu_frac = pair_evals * valu_per_eval / 64.0 / (avg_ms * 1e-3) / VALU_WAVE_INSTR_PEAK
+        traffic, traffic_note = None, None
+        try:   # HBM-side bytes per sweep launch from the committed rocprofv3 PMC passes (profiles/traffic.json)
+            tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+            ent = tj.get(f"{args.workload}:planes={planes}:n_iso={n_iso}:sweep={info['sweep_kind']}:gpus={world}")
+            if ent:
+                traffic, traffic_note = ent["bytes_per_launch"], ent["how"]
+        except (OSError, ValueError, KeyError):
+            pass
         out = {
             "metric": "range-block matches/sec (8x8 R, 16x16 D, 8 iso)" if (B == 8 and n_iso == 8) else
                       f"range-block matches/sec ({B}x{B} R, {2 * B}x{2 * B} D, {n_iso} iso)",
@@ -202,7 +219,7 @@ def main():
                        "N_r": Nr, "N_d": Nd, "pool_chunks": info["chunks"], "parallelism": f"range/plane shards x{world}"},
             "pair_evals_per_s": pair_evals * sweep_n / (sweep_ms * 1e-3) if sweep_ms > 0 else None,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,
                          "kernel": "k_sweep_fast", "avg_launch_ms": avg_ms, "launches": sweep_n,
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "note": "algorithmic bytes = ranges x N_d x (n+8); each wave keeps 64 range blocks in VGPRs "
