@@ -1,0 +1,97 @@
+"""BASELINE.json's full sizes (configs 3 and 4: 262 144 range blocks x 1 042 441 domain blocks).
+The oracle cannot sweep these, so parity is checked (a) on a handful of range blocks against the
+oracle over the FULL pool, and (b) through size-independent properties: the result of a range span
+does not depend on how the pool is chunked, which sweep kernel ran, or how ranges are sharded."""
+import numpy as np
+import pytest
+
+import fic_amd
+from fic_amd import synth
+from conftest import same_f32
+
+pytestmark = pytest.mark.gpu
+
+
+def _span(enc, b, c):
+    enc.encode(b, c)
+    r = enc.results()
+    return {k: v[0][b:b + c].copy() for k, v in r.items()}
+
+
+def _same(a, b):
+    for k in ("idx_local", "iso", "qrows", "idx_global"):
+        assert (a[k] == b[k]).all(), k
+    for k in ("a", "b", "err"):
+        assert same_f32(a[k], b[k]), k
+
+
+def _oracle_rows(oracle, g, B, wK, n_iso, rows):
+    argb = oracle.gray_to_argb(g)
+    h, w = g.shape
+    out = {}
+    for j in rows:
+        e = oracle.encode_gray(argb, w, h, B, wK, n_iso, j, j + 1)
+        out[j] = (int(e["info"][j, 0]), e["info"][j, 1:].copy(), int(e["iso"][j]), e["err"][j])
+    return out
+
+
+def test_cfg3_size_2048_B4(oracle):
+    g = synth.image_u(2048, 2048, synth.SEEDS["cfg3"])
+    with fic_amd.Encoder(2048, 2048, 4, None, 1) as enc:
+        assert (enc.n_ranges, enc.n_domains, enc.wK) == (262144, 1042441, 1021)
+        enc.set_gray(g)
+        b, c = 131072 - 256, 1024                      # a span in the middle of the image, tile aligned
+        enc.set_option("sweep", 2)
+        base = _span(enc, b, c)
+        for chunks in (1, 5, 64):
+            enc.set_option("chunks", chunks)
+            _same(_span(enc, b, c), base)
+        enc.set_option("chunks", 0)
+        parts = [_span(enc, b + o, n) for o, n in ((0, 256), (256, 512), (768, 256))]   # shards of the span
+        _same({k: np.concatenate([p[k] for p in parts]) for k in base}, base)
+        enc.set_option("sweep", 1)                     # generic exact kernel on a few ranges
+        _same(_span(enc, b, 8), {k: v[:8] for k, v in base.items()})
+    ref = _oracle_rows(oracle, g, 4, 1021, 1, [b, b + 517, b + 1023])
+    for j, (idx, ab, iso, err) in ref.items():
+        o = j - b
+        assert base["idx_local"][o] == idx and same_f32(np.array([base["a"][o], base["b"][o]]), ab)
+        assert same_f32(np.array([base["err"][o]]), np.array([err]))
+
+
+def test_cfg4_size_4096_B8_iso8(oracle):
+    g = synth.image_u(4096, 4096, synth.SEEDS["cfg4"])
+    with fic_amd.Encoder(4096, 4096, 8, None, 8) as enc:
+        assert (enc.n_ranges, enc.n_domains, enc.wK) == (262144, 1042441, 1021)
+        enc.set_gray(g)
+        b, c = 200000 - 200000 % 64, 512
+        enc.set_option("sweep", 2)
+        valu = _span(enc, b, c)
+        enc.set_option("chunks", 3)
+        _same(_span(enc, b, c), valu)
+        enc.set_option("chunks", 0)
+        enc.set_option("sweep", 3)                     # matrix-core sweep, same span
+        _same(_span(enc, b, c), valu)
+        enc.set_option("chunks", 7)
+        _same(_span(enc, b, c), valu)
+    ref = _oracle_rows(oracle, g, 8, 1021, 8, [b + 3, b + 400])
+    for j, (idx, ab, iso, err) in ref.items():
+        o = j - b
+        assert valu["idx_local"][o] == idx and valu["iso"][o] == iso
+        assert same_f32(np.array([valu["a"][o], valu["b"][o]]), ab)
+
+
+def test_cfg4_size_reference_algorithm_and_S_image(oracle):
+    """n_iso = 1 (the reference algorithm) on the adversarial S image at 4096x4096: flat blocks, rem == 0
+    ranges and exact ties at scale; the generic exact kernel must agree with the fast one."""
+    g = synth.image_s(4096, 4096, synth.SEEDS["cfg4"])
+    with fic_amd.Encoder(4096, 4096, 8, None, 1) as enc:
+        enc.set_gray(g)
+        b, c = 100000 - 100000 % 128, 512
+        enc.set_option("sweep", 2)
+        fast = _span(enc, b, c)
+        enc.set_option("sweep", 1)
+        _same(_span(enc, b, 16), {k: v[:16] for k, v in fast.items()})
+    ref = _oracle_rows(oracle, g, 8, 1021, 1, [b, b + 300])
+    for j, (idx, ab, iso, err) in ref.items():
+        o = j - b
+        assert fast["idx_local"][o] == idx and same_f32(np.array([fast["a"][o], fast["b"][o]]), ab)
