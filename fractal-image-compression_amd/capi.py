@@ -120,6 +120,25 @@ def decode_gray_run(run, device=0, avg_error_in=0.0):
     return out[:cap].reshape(h, w), np.float32(avg.value), it.value
 
 
+def encode_gray_oneshot(gray, B, wK, n_iso=1, device=0):
+    """The one-shot C entry point fic_encode_gray_u8 (host buffers in and out; what the JNI shim binds)."""
+    g = np.ascontiguousarray(gray, np.uint8)
+    h, w = g.shape
+    Rw, Rh, Dw, Dh = geometry(w, h, B)
+    nr = Rw * Rh
+    r = {"idx_local": np.zeros(nr, np.int32), "a": np.zeros(nr, np.float32), "b": np.zeros(nr, np.float32),
+         "iso": np.zeros(nr, np.int32), "qrows": np.zeros((nr, 3), np.int32)}
+    check(lib().fic_encode_gray_u8(ptr(g, C.c_uint8), w, h, B, Dw if wK is None else wK, n_iso, device,
+                                   ptr(r["idx_local"], C.c_int32), ptr(r["a"], C.c_float), ptr(r["b"], C.c_float),
+                                   ptr(r["iso"], C.c_int32), ptr(r["qrows"], C.c_int32)))
+    return r
+
+
+def release_cache():
+    lib().fic_release_cache.restype = None
+    lib().fic_release_cache()
+
+
 def decode_rgb_run(run, device=0, avg_error_in=0.0):
     """decodeRGB (FC:430-508) on the GPU.  Returns (argb int32 [H*W], avgError float32, iterations, w, h)."""
     L = lib()

@@ -144,6 +144,45 @@ int flush_events(fic_ctx* c)
     return FIC_OK;
 }
 
+// Idle single-plane contexts of the one-shot entry points, most recently used last.
+std::mutex g_cache_mu;
+std::vector<fic_ctx*> g_cache;
+constexpr size_t kCacheSlots = 4;
+
+fic_ctx* cache_take(int device, int w, int h, int B, int wK, int n_iso)
+{
+    std::lock_guard<std::mutex> lk(g_cache_mu);
+    for (size_t i = g_cache.size(); i-- > 0;) {
+        fic_ctx* c = g_cache[i];
+        const FicGeom& g = c->g;
+        if (c->device == device && g.W == w && g.H == h && g.B == B && g.wK == wK && g.n_iso == n_iso && g.planes == 1) {
+            g_cache.erase(g_cache.begin() + (long)i);
+            return c;
+        }
+    }
+    return nullptr;
+}
+
+}  // namespace
+
+extern "C" void fic_ctx_destroy(fic_ctx* c);
+
+namespace {
+
+void cache_give(fic_ctx* c)
+{
+    fic_ctx* evict = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_cache_mu);
+        g_cache.push_back(c);
+        if (g_cache.size() > kCacheSlots) {
+            evict = g_cache.front();
+            g_cache.erase(g_cache.begin());
+        }
+    }
+    if (evict) fic_ctx_destroy(evict);
+}
+
 }  // namespace
 
 extern "C" {
@@ -780,17 +819,31 @@ static int encode_oneshot(const uint8_t* gray, const int32_t* argb, int w, int h
                           int32_t* idx_local, float* a, float* b, int32_t* iso, int32_t* qrows)
 {
     if ((!gray && !argb) || !idx_local || !a || !b) return fail(FIC_E_ARGUMENT, "fic_encode_gray: null argument");
-    fic_ctx* c = fic_ctx_create(device, w, h, B, wK, n_iso, 1);
+    // The GUI calls encode once per slider move with the same geometry (CTL:125-145): keep the last few
+    // working sets instead of paying ~18 hipMalloc/hipFree per call.
+    fic_ctx* c = cache_take(device, w, h, B, wK, n_iso);
+    if (!c) c = fic_ctx_create(device, w, h, B, wK, n_iso, 1);
     if (!c) return g_err_code ? g_err_code : FIC_E_HIP;   // fic_ctx_create recorded why
     int rc = gray ? fic_ctx_set_gray_host(c, gray) : fic_ctx_set_argb_host(c, argb);
     if (rc == FIC_OK) rc = fic_ctx_encode(c, 0, -1, nullptr);
     if (rc == FIC_OK) rc = fic_ctx_get_results_host(c, idx_local, a, b, iso, qrows, nullptr, nullptr);
     std::string keep = g_err;
     int keep_code = g_err_code;
-    fic_ctx_destroy(c);
+    if (rc == FIC_OK) cache_give(c);
+    else fic_ctx_destroy(c);
     g_err = keep;
     g_err_code = keep_code;
     return rc;
+}
+
+void fic_release_cache(void)
+{
+    std::vector<fic_ctx*> drop;
+    {
+        std::lock_guard<std::mutex> lk(g_cache_mu);
+        drop.swap(g_cache);
+    }
+    for (fic_ctx* c : drop) fic_ctx_destroy(c);
 }
 
 int fic_encode_gray_argb(const int32_t* argb, int w, int h, int B, int wK, int n_iso, int device, int32_t* idx_local,

@@ -393,3 +393,21 @@ def test_context_decode_with_isometries_and_batches(oracle, n_iso):
         assert avg[p].view(np.uint32) == np.float32(wavg).view(np.uint32)
     if n_iso == 1:
         assert abs(oracle.psnr(dec[0], imgs[0]) - 24.823) < 1e-3
+
+
+def test_one_shot_context_cache_reuse(oracle):
+    """The one-shot entry keeps working sets per geometry: interleaved geometries and changing images
+    must give the same results as fresh contexts."""
+    from fic_amd import capi as _c
+    _c.release_cache()
+    imgs = [IMAGES["lena256"], IMAGES["S256"], IMAGES["U256"]]
+    for rep in range(2):
+        for g in imgs:
+            for B, wK, n_iso in [(8, 2, 1), (8, None, 8), (16, 16, 1), (4, None, 1), (8, 4, 8), (16, None, 8)]:
+                got = _c.encode_gray_oneshot(g, B, wK, n_iso)
+                Dw = fic_amd.geometry(256, 256, B)[2]
+                ref = _oracle_encode(oracle, g, B, Dw if wK is None else wK, n_iso)
+                assert (got["idx_local"] == ref["info"][:, 0].astype(np.int32)).all()
+                assert (got["iso"] == ref["iso"]).all()
+                assert same_f32(got["a"], ref["info"][:, 1]) and same_f32(got["b"], ref["info"][:, 2])
+    _c.release_cache()
