@@ -196,8 +196,9 @@ def main():
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
         pair_evals = float(ranges_per_step_rank) * Nd * n_iso
         # VALU instructions per pair evaluation of the sweep kernel (static count from the ISA):
-        # n/4 v_dot4 + cvt + cmp per isometry copy, + 3 per (range,domain) shared by the copies
-        valu_per_eval = n / 4 + 2 + 3.0 / (n_iso if n_iso > 1 else 1)
+        # n/4 v_dot4 per pair evaluation, plus per (range, domain): 1 iso -> 2 (base) + mul + cvt + cmp = 5;
+        # 8 iso -> 2 (base) + mul + cvt + 8 (max3/min3 reduction of the 8 copies) + sub + 2 cmp = 15, shared by 8
+        valu_per_eval = n / 4 + (15.0 / 8.0 if n_iso == 8 else 5.0)
         valu_frac = pair_evals * valu_per_eval / 64.0 / (avg_ms * 1e-3) / VALU_WAVE_INSTR_PEAK
         traffic, traffic_note = None, None
         try:   # HBM-side bytes per sweep launch from the committed rocprofv3 PMC passes (profiles/traffic.json)

@@ -411,7 +411,9 @@ __global__ __launch_bounds__(256) void k_sweep_fast(SweepArgs A)
             neg_rem[rs] = -st.rem;
             best_err[rs] = INFINITY;
             best_cand[rs] = 0xFFFFFFFFu;
-            tau[rs] = __uint_as_float(0x7FC00000u);     // NaN: first candidate always evaluated
+            // "nothing evaluated yet": NaN makes the f32 test fail; the integer test of the 8-copy variants
+            // starts from 0 and forces the chunk's first block instead
+            tau[rs] = NC >= 8 ? 0.0f : __uint_as_float(0x7FC00000u);
         }
     }
 
@@ -443,41 +445,74 @@ __global__ __launch_bounds__(256) void k_sweep_fast(SweepArgs A)
             for (int k = 0; k < NC; k++) acc[rs][k] = base;
         }
     };
-    auto end_domain = [&](int d, const u32x2& s) {
-        float s32 = __uint_as_float(s.y);
-        bool any = false;
-        bool flag[NR][NC];
-#pragma unroll
-        for (int rs = 0; rs < NR; rs++) {
-            float lim = __fmul_rn(tau[rs], s32);
-#pragma unroll
-            for (int k = 0; k < NC; k++) {
-                float cf = fabsf((float)(int)acc[rs][k]);
-                flag[rs][k] = !(cf <= lim);            // NaN lim -> evaluate
-                any |= flag[rs][k];
-            }
+    // exact epilogue of one (range, copy, domain): strict '<' in ascending candidate order (FC:627), then raise tau:
+    // any later candidate with |cov'|/sqrt(var') <= (1-2^-18) * |cov|/sqrt(var) has |r'| <= |r|, hence
+    // error' >= error >= best, and can be skipped.
+    auto evaluate = [&](int rs, int k, int d, float s32, double s64) {
+        const int cov = (int)acc[rs][k];
+        const float e = exact_error(cov, -neg_rem[rs], s64);
+        if (e < best_err[rs]) {
+            best_err[rs] = e;
+            best_cand[rs] = (uint32_t)d * (uint32_t)A.n_iso + (uint32_t)(kbase + k);
         }
-        if (__builtin_expect(__any(any), 0)) {
-            double s64 = s64p[d];
+        const float lvl = (s32 == 0.0f) ? 0.0f : __fmul_rn(__fdiv_rn(fabsf((float)cov), s32), 0.99999618530273437500f);
+        const float t = tau[rs];
+        tau[rs] = (t != t) ? lvl : fmaxf(t, lvl);
+    };
+    auto end_domain = [&](int d, const u32x2& s) {
+        const float s32 = __uint_as_float(s.y);
+        if constexpr (NC >= 8) {
+            // 8 isometry copies share rem/tau: reduce their covariances with integer max/min and test the two
+            // extremes once --  |cov| > tau*s32  <=>  cov > li or cov < -li  with  li = floor(tau*s32)  (cov integer).
+            const bool force = (d == d0);              // wave-uniform: the chunk's first block initialises tau
+            bool any = force;
+            int li[NR];
 #pragma unroll
             for (int rs = 0; rs < NR; rs++) {
+                li[rs] = (int)__fmul_rn(tau[rs], s32);  // tau <= 8192, s32 <= 4080: exact floor, far below 2^31
+                int mx = (int)acc[rs][0], mn = mx;
+#pragma unroll
+                for (int k = 1; k < NC; k++) {
+                    mx = max(mx, (int)acc[rs][k]);
+                    mn = min(mn, (int)acc[rs][k]);
+                }
+                any |= (mx > li[rs]) | (mn < -li[rs]);
+            }
+            if (__builtin_expect(__any(any), 0)) {
+                const double s64 = s64p[d];
+#pragma unroll
+                for (int rs = 0; rs < NR; rs++) {
+#pragma unroll
+                    for (int k = 0; k < NC; k++) {
+                        const int cov = (int)acc[rs][k];
+                        if (force || cov > li[rs] || cov < -li[rs]) evaluate(rs, k, d, s32, s64);
+                    }
+                    // rem == 0: error 0 for every block (FC:677); 8192 >= |cov|/sqrt(var) for any pair
+                    if (neg_rem[rs] == 0 && best_cand[rs] != 0xFFFFFFFFu) tau[rs] = 8192.0f;
+                }
+            }
+        } else {
+            bool any = false;
+            bool flag[NR][NC];
+#pragma unroll
+            for (int rs = 0; rs < NR; rs++) {
+                const float lim = __fmul_rn(tau[rs], s32);
 #pragma unroll
                 for (int k = 0; k < NC; k++) {
-                    if (flag[rs][k]) {
-                        int cov = (int)acc[rs][k];
-                        float e = exact_error(cov, -neg_rem[rs], s64);
-                        if (e < best_err[rs]) {        // strict '<', ascending candidate order (FC:627)
-                            best_err[rs] = e;
-                            best_cand[rs] = (uint32_t)d * (uint32_t)A.n_iso + (uint32_t)(kbase + k);
-                        }
-                        // Any later candidate with |cov'|/sqrt(var') <= (1-2^-18) * |cov|/sqrt(var) has
-                        // |r'| <= |r| hence error' >= error >= best: it can be skipped.
-                        float lvl = (s32 == 0.0f) ? 0.0f : __fmul_rn(__fdiv_rn(fabsf((float)cov), s32), 0.99999618530273437500f);
-                        float t = tau[rs];
-                        tau[rs] = (t != t) ? lvl : fmaxf(t, lvl);
-                    }
+                    const float cf = fabsf((float)(int)acc[rs][k]);
+                    flag[rs][k] = !(cf <= lim);        // NaN lim -> evaluate
+                    any |= flag[rs][k];
                 }
-                if (neg_rem[rs] == 0 && best_cand[rs] != 0xFFFFFFFFu) tau[rs] = 3.402823466e+38f;
+            }
+            if (__builtin_expect(__any(any), 0)) {
+                const double s64 = s64p[d];
+#pragma unroll
+                for (int rs = 0; rs < NR; rs++) {
+#pragma unroll
+                    for (int k = 0; k < NC; k++)
+                        if (flag[rs][k]) evaluate(rs, k, d, s32, s64);
+                    if (neg_rem[rs] == 0 && best_cand[rs] != 0xFFFFFFFFu) tau[rs] = 3.402823466e+38f;
+                }
             }
         }
     };
