@@ -414,11 +414,20 @@ int fic_ctx_encode(fic_ctx* c, int range_begin, int range_count, void* hip_strea
         long long base_waves = (long long)ntiles * (g.n_iso / NC) * g.planes;
         nchunks = c->opt_chunks;
         if (nchunks <= 0) {
-            long long want = (32768 + base_waves - 1) / base_waves;
-            long long cap = g.Nd / 2048;
+            // Measured (profiles/r01l_chunk_sweep.txt): every chunk pays a start-up (its first block is evaluated
+            // exactly and tau restarts), so chunks stay >= 4096 blocks while aiming at ~48 K wave tasks for load
+            // balance; only a launch that could not otherwise fill the chip (one small image) splits finer.
+            long long want = (49152 + base_waves - 1) / base_waves;
+            long long cap = g.Nd / 4096;
             if (cap < 1) cap = 1;
-            nchunks = (int)(want < cap ? want : cap);
-            if (nchunks < 1) nchunks = 1;
+            long long nc = want < cap ? want : cap;
+            if (base_waves * nc < 4096) {
+                long long cap2 = g.Nd / 512;
+                if (cap2 < 1) cap2 = 1;
+                long long fill = (4096 + base_waves - 1) / base_waves;
+                nc = fill < cap2 ? fill : cap2;
+            }
+            nchunks = (int)(nc < 1 ? 1 : nc);
         }
         if (nchunks > g.Nd) nchunks = g.Nd;
         int chunk_len = (g.Nd + nchunks - 1) / nchunks;
