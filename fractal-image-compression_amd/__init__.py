@@ -6,7 +6,7 @@ mirror of the reference's interface plus the multi-GPU plumbing.
 """
 from . import capi, synth, sharding
 from .capi import FicError, declared_symbols, geometry, write_run_gray, decode_gray_run, decode_rgb_run, encode_rgb, write_run_rgb
-from .host import Encoder, FractalCompression, RasterImage, encode_gray
+from .host import Encoder, FractalCompression, RasterImage, encode_gray, encode_rgb_per_channel
 from .sharding import ShardedEncoder, shard_spans, shard_planes, gather_records, pack_records, unpack_records
 
 __all__ = ["capi", "synth", "sharding", "FicError", "declared_symbols", "geometry", "write_run_gray", "decode_gray_run", "decode_rgb_run", "encode_rgb", "write_run_rgb", "Encoder",

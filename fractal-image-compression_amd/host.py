@@ -190,6 +190,24 @@ class Encoder:
         return {"pix": pix, "sum": s, "var": v, "scaled": sc}
 
 
+def encode_rgb_per_channel(rgb, B, wK=None, n_iso=1, device=0, sweep=0):
+    """BASELINE.json config 5: a batch of colour images encoded as 3 independent grey planes each (NOT the
+    reference's joint-RGB fit, which is `capi.encode_rgb`).  rgb: uint8 [N,H,W,3] (or [H,W,3]).
+    Returns the result dict with arrays shaped [N, 3, N_r] (qrows [N, 3, N_r, 3]); channel order R, G, B."""
+    a = np.ascontiguousarray(rgb, np.uint8)
+    if a.ndim == 3:
+        a = a[None]
+    n, h, w, _ = a.shape
+    planes = np.ascontiguousarray(a.transpose(0, 3, 1, 2)).reshape(n * 3, h, w)
+    with Encoder(w, h, B, wK, n_iso, n * 3, device) as enc:
+        if sweep:
+            enc.set_option("sweep", sweep)
+        enc.set_gray(planes)
+        enc.encode()
+        r = enc.results()
+    return {k: v.reshape((n, 3) + v.shape[1:]) for k, v in r.items()}
+
+
 def encode_gray(gray, B, wK=None, n_iso=1, device=0, sweep=0, chunks=0):
     """One grey image (uint8 [H,W]) -> result dict with [N_r] arrays (plane axis dropped)."""
     g = np.ascontiguousarray(gray, np.uint8)

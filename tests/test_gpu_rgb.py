@@ -113,3 +113,17 @@ def test_k1_stream_decodes_through_the_mirror(oracle):
     rgb = np.stack([(u >> 16) & 0xFF, (u >> 8) & 0xFF, u & 0xFF], axis=-1).astype(np.uint8).reshape(256, 256, 3)
     assert (rgb == want).all() and fc.getAvgError() == wavg
     assert (img.argb.view(np.uint32) >> 24 == 0xFF).all()
+
+
+def test_config5_per_channel_encode(lena_colored, oracle):
+    """Config 5's "RGB, per-channel encode": three independent grey planes per image."""
+    batch = np.stack([lena_colored[:128, :128], lena_colored[128:, 128:]])
+    got = fic_amd.encode_rgb_per_channel(batch, 8, None, 8)
+    assert got["idx_local"].shape == (2, 3, 256)
+    for i in range(2):
+        for c in range(3):
+            g = np.ascontiguousarray(batch[i, :, :, c])
+            ref = oracle.encode_gray(oracle.gray_to_argb(g), 128, 128, 8, 29, 8)
+            assert (got["idx_local"][i, c] == ref["info"][:, 0].astype(np.int32)).all()
+            assert (got["iso"][i, c] == ref["iso"]).all()
+            assert same_f32(got["a"][i, c], ref["info"][:, 1]) and same_f32(got["b"][i, c], ref["info"][:, 2])
