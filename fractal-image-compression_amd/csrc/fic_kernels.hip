@@ -258,32 +258,43 @@ __global__ __launch_bounds__(256) void k_range_stat(const uint8_t* __restrict__ 
 
 // (b) pixels: one thread per output dword (range j, isometry copy k, dword dw); consecutive threads are
 // consecutive lanes of the lane-transposed store, so every wave writes one coalesced 256-byte run.
+// One workgroup per group of 64 range blocks (one "rs" slice of a tile): the blocks are read word-wise
+// into LDS (row stride n+4 bytes: bank-conflict-free for the byte gathers), then every output dword of
+// every isometry copy is assembled from 4 LDS bytes and written as part of a coalesced 256-byte run.
 __global__ __launch_bounds__(256) void k_range_copies(const uint8_t* __restrict__ gray, uint32_t* __restrict__ rng_pix, FicGeom g)
 {
+    __shared__ __attribute__((aligned(16))) uint8_t blk[64 * (256 + 4)];
     const int plane = blockIdx.y;
-    const size_t per_plane = (size_t)g.Nr_pad * g.n_iso * g.DW;
-    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;        // index into rng_pix[plane]: [tile][rs][k][dw][lane]
-    if (i >= per_plane) return;
-    const int lane = (int)(i & 63);
-    size_t r = i >> 6;
-    const int dw = (int)(r % g.DW); r /= g.DW;
-    const int k = (int)(r % g.n_iso); r /= g.n_iso;
-    const int rs = (int)(r % g.NR);
-    const int tile = (int)(r / g.NR);
-    const int j = (tile * g.NR + rs) * 64 + lane;
-    uint32_t w = 0;
-    if (j < g.Nr) {                                           // tile padding stays zero (never written back)
-        const int B = g.B;
-        const uint8_t* im = gray + (size_t)plane * g.W * g.H + (size_t)((j / g.Rw) * B) * g.W + (j % g.Rw) * B;
+    const int grp = blockIdx.x;                                // (tile, rs)
+    const int B = g.B, n = g.n, DW = g.DW;
+    const int stride = n + 4;
+    const int j0 = grp * 64;
+    const uint8_t* img = gray + (size_t)plane * g.W * g.H;
+    for (int i = threadIdx.x; i < 64 * DW; i += 256) {         // DW words per block
+        const int lane = i / DW, wd = i % DW;
+        const int j = j0 + lane;
+        uint32_t v = 0;
+        if (j < g.Nr) {                                        // tile padding stays zero (never written back)
+            const int pos = wd * 4;
+            const uint8_t* p = img + (size_t)((j / g.Rw) * B + pos / B) * g.W + (j % g.Rw) * B + pos % B;
+            v = *(const uint32_t*)p;                           // B, W multiples of 4: aligned
+        }
+        *(uint32_t*)&blk[lane * stride + wd * 4] = v;
+    }
+    __syncthreads();
+    uint32_t* out = rng_pix + (size_t)plane * g.Nr_pad * g.n_iso * DW + (size_t)grp * g.n_iso * DW * 64;
+    for (int o = threadIdx.x; o < g.n_iso * DW * 64; o += 256) {   // [k][dw][lane]; k, dw are wave-uniform
+        const int lane = o & 63, dw = (o >> 6) % DW, k = (o >> 6) / DW;
         const int ki = iso_inverse(k);
+        const uint8_t* b = blk + lane * stride;
+        uint32_t w = 0;
 #pragma unroll
         for (int t = 0; t < 4; t++) {
             const int pos = dw * 4 + t;
-            const int src = iso_source(ki, B, pos % B, pos / B);
-            w |= (uint32_t)im[(size_t)(src / B) * g.W + (src % B)] << (8 * t);
+            w |= (uint32_t)b[iso_source(ki, B, pos % B, pos / B)] << (8 * t);
         }
+        out[o] = w;
     }
-    rng_pix[(size_t)plane * per_plane + i] = w;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1189,8 +1200,7 @@ int fic_launch_range(const uint8_t* gray, uint32_t* rng_pix, FicRngStat* rst, co
 {
     hipLaunchKernelGGL(k_range_stat, dim3((g.Nr_pad + 255) / 256, g.planes), dim3(256), 0, s, gray, rst, g);
     FIC_LAUNCH_CHECK();
-    size_t per_plane = (size_t)g.Nr_pad * g.n_iso * g.DW;
-    hipLaunchKernelGGL(k_range_copies, dim3((unsigned)((per_plane + 255) / 256), g.planes), dim3(256), 0, s, gray, rng_pix, g);
+    hipLaunchKernelGGL(k_range_copies, dim3(g.tiles * g.NR, g.planes), dim3(256), 0, s, gray, rng_pix, g);
     FIC_LAUNCH_CHECK();
     return 0;
 }
