@@ -242,11 +242,11 @@ def main():
                                "unit": "TOP/s", "frac": ops / (avg_ms * 1e-3) / 1e12 / 5000.0, "traffic": None,
                                "kernel": "k_sweep_mfma", "avg_launch_ms": avg_ms, "launches": sweep_n,
                                "note": "opt-in (--sweep 3): north_star rules MFMA out for this path; default is the VALU sweep"}
-            vpe = 3.5
+            vpe = 3.5 if n_iso == 8 else 6.0
             out["valu"] = {"bound": "valu-issue (epilogue)", "valu_instr_per_pair_eval": vpe,
                            "frac": pair_evals * vpe / 64.0 / (avg_ms * 1e-3) / VALU_WAVE_INSTR_PEAK,
                            "peak_wave_instr_per_s": VALU_WAVE_INSTR_PEAK}
-        if info["sweep_kind"] == 2 and B == 8 and n_iso == 8 and world == 1 and not args.no_alt:
+        if info["sweep_kind"] == 2 and ((B == 8 and n_iso == 8) or n_iso == 1) and world == 1 and not args.no_alt:
             # Same workload, same buffers, through the opt-in matrix-core sweep: reported beside, never as `value`.
             core.set_option("sweep", 3)
             for _ in range(args.warmup):
@@ -261,7 +261,8 @@ def main():
             ms3, n3 = core.sweep_time(reset=True)
             core.set_option("sweep", 0)
             out["opt_in_matrix_core"] = {
-                "how": "bench.py --sweep 3 / fic_ctx_set_option(ctx, \"sweep\", 3)", "kernel": "k_sweep_mfma",
+                "how": "bench.py --sweep 3 / fic_ctx_set_option(ctx, \"sweep\", 3)",
+                "kernel": "k_sweep_mfma" if n_iso == 8 else "k_sweep_mfma1",
                 "value": total_ranges / dt3, "unit": "range-block matches/s", "ms_per_step": dt3 / args.steps * 1e3,
                 "avg_launch_ms": ms3 / max(n3, 1), "speedup_vs_default": dt / dt3,
                 "note": "bit-identical codebooks (tests/test_gpu_mfma.py); inner products on v_mfma_i32_32x32x32_i8. "

@@ -95,6 +95,7 @@ struct fic_ctx {
     uint8_t* decoded = nullptr;      // decoder output image(s)
     void* mfma_poolB = nullptr;      // opt-in matrix-core sweep: B fragments, A fragments, range constants
     void* mfma_rngA = nullptr;
+    void* mfma_sw = nullptr;
     int* mfma_rconst = nullptr;
     bool have_input = false;
     bool encoded_any = false;
@@ -121,7 +122,7 @@ int ctx_free_all(fic_ctx* c)
     hipSetDevice(c->device);
     for (hipEvent_t e : c->ev) hipEventDestroy(e);
     c->ev.clear();
-    void* ptrs[] = {c->gray_own, c->argb_stage, c->collage, c->decoded, c->mfma_poolB, c->mfma_rngA, c->mfma_rconst, c->b.scaled, c->b.pool_pix, c->b.pool_st, c->b.pool_var,
+    void* ptrs[] = {c->gray_own, c->argb_stage, c->collage, c->decoded, c->mfma_poolB, c->mfma_rngA, c->mfma_sw, c->mfma_rconst, c->b.scaled, c->b.pool_pix, c->b.pool_st, c->b.pool_var,
                     c->b.pool_s64, c->b.rng_pix, c->b.rng_st, c->b.key, c->o.idx_local, c->o.idx_global, c->o.iso,
                     c->o.a, c->o.b, c->o.err, c->o.qrows};
     for (void* p : ptrs)
@@ -356,8 +357,8 @@ int fic_ctx_encode(fic_ctx* c, int range_begin, int range_count, void* hip_strea
     int kind = c->opt_sweep;
     if (kind == 0) kind = g.full ? 2 : 1;
     if (kind >= 2 && !g.full) return fail(FIC_E_ARGUMENT, "fast sweep needs full search (wK == Dw == Dh)");
-    if (kind == 3 && !(g.B == 8 && g.n_iso == 8))
-        return fail(FIC_E_ARGUMENT, "the matrix-core sweep is built for B = 8, n_iso = 8 only");
+    if (kind == 3 && !((g.B == 8 && g.n_iso == 8) || g.n_iso == 1))
+        return fail(FIC_E_ARGUMENT, "the matrix-core sweep is built for n_iso = 1 (B = 4, 8, 16) and for B = 8, n_iso = 8");
     const int tsz = 64 * g.NR;
     const int tile0 = range_begin / tsz;
     const int tile1 = (range_begin + range_count + tsz - 1) / tsz;
@@ -377,16 +378,31 @@ int fic_ctx_encode(fic_ctx* c, int range_begin, int range_count, void* hip_strea
     } else if (kind == 3) {
         const int ndtiles = (g.Nd + 31) / 32, ndtiles_alloc = ndtiles + 1;
         const size_t P = (size_t)g.planes;
+        const bool iso8 = g.n_iso == 8;
+        const int NM = g.n <= 32 ? 1 : g.n / 32;                      // K = 32 MFMA steps per block
+        const int nctiles = g.Nr_pad / 32, nctiles_alloc = nctiles + 32; // column tiles (x32 ranges), n_iso = 1 kernel
         if (!c->mfma_poolB) {
-            HIP_TRY(hipMalloc(&c->mfma_poolB, P * ndtiles_alloc * 128 * 16));
-            HIP_TRY(hipMalloc(&c->mfma_rngA, P * g.tiles * FIC_MFMA_RT_HOST * 128 * 16));
-            HIP_TRY(hipMalloc((void**)&c->mfma_rconst, P * g.tiles * FIC_MFMA_RT_HOST * 16 * sizeof(int)));
+            if (iso8) {
+                HIP_TRY(hipMalloc(&c->mfma_poolB, P * ndtiles_alloc * 128 * 16));
+                HIP_TRY(hipMalloc(&c->mfma_rngA, P * g.tiles * FIC_MFMA_RT_HOST * 128 * 16));
+                HIP_TRY(hipMalloc((void**)&c->mfma_rconst, P * g.tiles * FIC_MFMA_RT_HOST * 16 * sizeof(int)));
+            } else {
+                HIP_TRY(hipMalloc(&c->mfma_poolB, P * ndtiles_alloc * NM * 64 * 16));
+                HIP_TRY(hipMalloc(&c->mfma_sw, P * ndtiles_alloc * 32 * 8));
+                HIP_TRY(hipMalloc(&c->mfma_rngA, P * nctiles_alloc * NM * 64 * 16));
+                HIP_TRY(hipMalloc((void**)&c->mfma_rconst, P * nctiles_alloc * 32 * 16));
+            }
         }
         // the fragment prep belongs to the pool build / range prep, not to the timed sweep
         if (c->opt_time) { hipEventDestroy(e0); hipEventDestroy(e1); e0 = e1 = nullptr; }
-        if (fic_launch_mfma_prep_pool(c->b.pool_pix, c->mfma_poolB, g, ndtiles_alloc, s) ||
-            fic_launch_mfma_prep_range(c->b.rng_pix, c->b.rng_st, c->mfma_rngA, c->mfma_rconst, g, s))
-            return fail(FIC_E_HIP, "mfma prep launch failed");
+        if (iso8) {
+            if (fic_launch_mfma_prep_pool(c->b.pool_pix, c->mfma_poolB, g, ndtiles_alloc, s) ||
+                fic_launch_mfma_prep_range(c->b.rng_pix, c->b.rng_st, c->mfma_rngA, c->mfma_rconst, g, s))
+                return fail(FIC_E_HIP, "mfma prep launch failed");
+        } else if (fic_launch_mfma1_prep(c->b, c->mfma_poolB, c->mfma_sw, c->mfma_rngA, c->mfma_rconst, g, ndtiles_alloc,
+                                         nctiles_alloc, s)) {
+            return fail(FIC_E_HIP, "mfma1 prep launch failed");
+        }
         if (c->opt_time) {
             HIP_TRY(hipEventCreate(&e0));
             HIP_TRY(hipEventCreate(&e1));
@@ -394,7 +410,8 @@ int fic_ctx_encode(fic_ctx* c, int range_begin, int range_count, void* hip_strea
         }
         nchunks = c->opt_chunks;
         if (nchunks <= 0) {
-            long long base_wg = (long long)ntiles * g.planes;        // workgroups per chunk (256 CUs x ~4 resident)
+            long long base_wg = iso8 ? (long long)ntiles * g.planes   // workgroups per chunk (256 CUs x ~4 resident)
+                                     : ((long long)ntiles * tsz / 32 + fic_mfma1_ct(g.B) - 1) / fic_mfma1_ct(g.B) * g.planes;
             long long want = (4096 + base_wg - 1) / base_wg;
             long long cap = ndtiles / 256;                            // >= 256 domain tiles per chunk: start-up cost < 10 %
             if (cap < 1) cap = 1;
@@ -405,9 +422,16 @@ int fic_ctx_encode(fic_ctx* c, int range_begin, int range_count, void* hip_strea
         int tiles_per_chunk = (ndtiles + nchunks - 1) / nchunks;
         nchunks = (ndtiles + tiles_per_chunk - 1) / tiles_per_chunk;
         if (nchunks > 65535) return fail(FIC_E_ARGUMENT, "too many chunks (%d)", nchunks);
-        if (fic_launch_sweep_mfma(c->b, c->mfma_poolB, c->mfma_rngA, c->mfma_rconst, g, tile0, ntiles, ndtiles, ndtiles_alloc,
-                                  tiles_per_chunk, nchunks, s))
-            return fail(FIC_E_HIP, "k_sweep_mfma launch failed");
+        if (iso8) {
+            if (fic_launch_sweep_mfma(c->b, c->mfma_poolB, c->mfma_rngA, c->mfma_rconst, g, tile0, ntiles, ndtiles,
+                                      ndtiles_alloc, tiles_per_chunk, nchunks, s))
+                return fail(FIC_E_HIP, "k_sweep_mfma launch failed");
+        } else {
+            const int ct_begin = tile0 * (tsz / 32), ct_end = tile1 * (tsz / 32);
+            if (fic_launch_sweep_mfma1(c->b, c->mfma_poolB, c->mfma_sw, c->mfma_rngA, c->mfma_rconst, g, ct_begin, ct_end,
+                                       ndtiles, ndtiles_alloc, nctiles_alloc, tiles_per_chunk, nchunks, s))
+                return fail(FIC_E_HIP, "k_sweep_mfma1 launch failed");
+        }
     } else {
         int NR, NC;
         fic_fast_variant(g.B, g.n_iso, &NR, &NC);

@@ -8,11 +8,14 @@
 //   k_argb_to_gray   RasterImage.argb -> R channel bytes          (FC:596, FC:977)
 //   k_scale          2:1 box average                              (scaleImage     FC:970-1007)
 //   k_pool           expanded domain pool + per-block sum/var     (createCodebuch FC:1015-1050, DB:23-29,92-115)
-//   k_range          range blocks, rM/rem, isometry copies        (getRangeblock FC:588-602, getMittelwert FC:67-73)
-//   k_sweep_fast     full-pool search, lane = range block         (getBestDomainblock FC:613-632 + getErrorVarianceCovariance FC:655-687)
+//   k_range_stat / k_range_copies   range blocks: rM/rem, isometry copies   (getRangeblock FC:588-602, getMittelwert FC:67-73)
+//   k_sweep_fast     full-pool search, lane = range block (DEFAULT) (getBestDomainblock FC:613-632 + getErrorVarianceCovariance FC:655-687)
 //   k_sweep_generic  any window, wave = range block               (same, + getDomainBlockIndex FC:516-545, generateKernel FC:84-100)
+//   k_sweep_mfma     opt-in matrix-core full-pool search (+ k_pool_mfma, k_range_mfma fragment prep)
 //   k_finalize       (a,b) fit, clamp, quantise                   (FC:634-642, writeData FC:242-244)
 //   k_collage        one-step collage image                       (getBestGeneratedCollage FC:269-300)
+// Decoder:  k_decode_paint / k_decode_paint_rgb / k_decode_step   (decodeGreyScale FC:356-421, decodeRGB FC:430-508)
+// Joint RGB: k_scale_rgb, k_pool_rgb, k_range_rgb, k_sweep_rgb, k_finalize_rgb, k_collage_rgb (encodeRGB FC:171-219 ...)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <math.h>
@@ -777,6 +780,182 @@ __global__ __launch_bounds__(256) void k_sweep_mfma(MfmaArgs A)
 }
 
 // ---------------------------------------------------------------------------------------------
+// k_sweep_mfma1 : OPT-IN matrix-core sweep for the reference algorithm (n_iso = 1), B = 4 / 8 / 16
+// ("sweep" = 3).  Same exactness scheme as k_sweep_mfma; the mapping is transposed:
+//   rows (A) = 32 consecutive domain blocks, streamed; cols (B) = 32 range blocks, fixed in LDS.
+//   col = lane&31 is the lane's range block: its constants {K, A, negR} and its tau come from
+//   LDS with one ds_read_b128 per column tile (tau is raised there by the exact path with
+//   ds_max_u32, so the two lane halves of a column see each other's updates).
+//   row = (e&3) + 8(e>>2) + 4(lane>>5) is register e's domain block: {sum, 1/sqrt(var)} of the
+//   lane's 16 rows are loaded once per domain tile (stored per tile in exactly that order).
+//   NM = n/32 MFMA steps of K = 32 (B = 4: one step, upper half of K zero).
+// Prune test per pair (f32):  |cov| * fl(1/s32) > tau  -- same 2^-18 margin as everywhere
+// (the extra 1/s32 rounding adds 2^-24); flat blocks carry w = 0 and are never flagged.
+// ---------------------------------------------------------------------------------------------
+struct Mfma1Args {
+    const v4i* poolA;                // [plane][ndtiles_alloc][NM][64]  domain fragments (i8-shifted)
+    const uint2* pool_sw;            // [plane][ndtiles_alloc][2][16]   {sum, 1/s32 bits} in accumulator-row order
+    const FicDomStat* pool_st;
+    const double* pool_s64;
+    const v4i* rngB;                 // [plane][nctiles_alloc][NM][64]  range fragments
+    const int4* rconst;              // [plane][nctiles_alloc*32]       {K, A, negR, tau0 bits}
+    unsigned long long* key;
+    int Nd, Nd_pad, Nr, Nr_pad, lgn;
+    int ndtiles, ndtiles_alloc, nctiles_alloc;
+    int ct_begin, ct_end;            // column tiles (x32 ranges) of this shard
+    int tiles_per_chunk, nchunks;
+};
+
+template <int NM>
+__global__ __launch_bounds__(256) void k_sweep_mfma1(Mfma1Args A)
+{
+    constexpr int CT = NM == 1 ? 32 : NM == 2 ? 16 : 4;      // column tiles per workgroup (32 KiB of fragments)
+    constexpr int CTW = CT / 4;                              // per wave
+    __shared__ v4i sB[CT * NM * 64];
+    __shared__ int4 sC[CT * 32];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int plane = blockIdx.z;
+    const int ct0 = A.ct_begin + blockIdx.x * CT;            // first column tile of the workgroup
+    const size_t cbase = (size_t)plane * A.nctiles_alloc + ct0;
+    for (int i = threadIdx.x; i < CT * NM * 64; i += 256) sB[i] = A.rngB[cbase * NM * 64 + i];
+    for (int i = threadIdx.x; i < CT * 32; i += 256) sC[i] = A.rconst[cbase * 32 + i];
+    __syncthreads();
+    const int chunk = blockIdx.y;
+    const int dt0 = chunk * A.tiles_per_chunk;
+    int dt1 = dt0 + A.tiles_per_chunk;
+    if (dt1 > A.ndtiles) dt1 = A.ndtiles;
+    if (dt0 >= dt1 || ct0 + wave * CTW >= A.ct_end) return;
+
+    const int jcol = lane & 31, half = lane >> 5;
+    const v4i* pa = A.poolA + (size_t)plane * A.ndtiles_alloc * NM * 64;
+    const uint4* psw = (const uint4*)(A.pool_sw + (size_t)plane * A.ndtiles_alloc * 32);
+    const FicDomStat* pst = A.pool_st + (size_t)plane * A.Nd_pad;
+    const double* p64 = A.pool_s64 + (size_t)plane * A.Nd_pad;
+    unsigned long long* keyp = A.key + (size_t)plane * A.Nr_pad;
+    const v16i zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+
+    for (int dt = dt0; dt < dt1; dt++) {
+        v4i a[NM];
+#pragma unroll
+        for (int m = 0; m < NM; m++) a[m] = pa[((size_t)dt * NM + m) * 64 + lane];
+        int Sd[16], dM[16];
+        float wd[16];
+#pragma unroll
+        for (int v = 0; v < 8; v++) {                        // 16 x {sum, w} of this half's accumulator rows
+            const uint4 s4 = psw[((size_t)dt * 2 + half) * 8 + v];
+            Sd[2 * v] = (int)s4.x;     wd[2 * v] = __uint_as_float(s4.y);
+            Sd[2 * v + 1] = (int)s4.z; wd[2 * v + 1] = __uint_as_float(s4.w);
+        }
+#pragma unroll
+        for (int e = 0; e < 16; e++) dM[e] = Sd[e] >> A.lgn;
+        const bool force = (dt == dt0);                      // wave-uniform
+
+        for (int ci = 0; ci < CTW; ci++) {
+            const int ctl = wave * CTW + ci;                 // column tile inside the workgroup
+            if (ct0 + ctl >= A.ct_end) break;                // wave-uniform
+            v16i acc = zero;
+#pragma unroll
+            for (int m = 0; m < NM; m++)
+                acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[m], sB[(ctl * NM + m) * 64 + lane], acc, 0, 0, 0);
+            const int4 c = sC[ctl * 32 + jcol];              // {K, A, negR, tau}
+            const float tau = __int_as_float(c.w);
+            int cov[16];
+            bool any = false;
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                int lin;
+                asm("v_mul_i32_i24 %0, %1, %2" : "=v"(lin) : "v"(c.z), "v"(dM[e]));
+                asm("v_mad_i32_i24 %0, %1, %2, %0" : "+v"(lin) : "v"(c.y), "v"(Sd[e]));
+                cov[e] = acc[e] + lin + c.x;                 // kovarianz, exact
+                any |= __fmul_rn(fabsf((float)cov[e]), wd[e]) > tau;
+            }
+            if (__builtin_expect(__any(any || force), 0)) {
+                const int j = (ct0 + ctl) * 32 + jcol;       // the lane's range block
+                const int rem = -c.z;
+#pragma unroll
+                for (int e = 0; e < 16; e++) {
+                    const int d = dt * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
+                    if ((force || __fmul_rn(fabsf((float)cov[e]), wd[e]) > tau) && d < A.Nd && j < A.Nr) {
+                        const float err = exact_error(cov[e], rem, p64[d]);
+                        atomicMin(&keyp[j], ((unsigned long long)f32_orderable(err) << 32) | (uint32_t)d);
+                        if (rem != 0) {
+                            const float s32 = pst[d].s32;
+                            const float lvl = (s32 == 0.0f) ? 0.0f
+                                                            : __fmul_rn(__fdiv_rn(fabsf((float)cov[e]), s32), 0.99999618530273437500f);
+                            atomicMax((unsigned int*)&sC[ctl * 32 + jcol].w, __float_as_uint(lvl));
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+// fragment prep for k_sweep_mfma1: domain fragments + per-row {sum, 1/s32} in accumulator-row order
+__global__ __launch_bounds__(256) void k_pool_mfma1(const uint8_t* __restrict__ pool_pix, const FicDomStat* __restrict__ pool_st,
+                                                    v4i* __restrict__ poolA, uint2* __restrict__ pool_sw, FicGeom g,
+                                                    int ndtiles_alloc, int NM)
+{
+    int i = blockIdx.x * 256 + threadIdx.x;                  // (dtile, m, lane)
+    int plane = blockIdx.y;
+    if (i >= ndtiles_alloc * NM * 64) return;
+    int lane = i & 63, m = (i >> 6) % NM, dtile = (i >> 6) / NM;
+    int d = dtile * 32 + (lane & 31), h = lane >> 5;
+    int off = 32 * m + 16 * h;
+    v4i v = {0, 0, 0, 0};                                    // i8 zeros: padding contributes nothing
+    if (d < g.Nd && off < g.n) {
+        v = *(const v4i*)(pool_pix + ((size_t)plane * g.Nd_pad + d) * g.n + off);
+        v ^= (v4i){(int)0x80808080, (int)0x80808080, (int)0x80808080, (int)0x80808080};
+    }
+    poolA[(size_t)plane * ndtiles_alloc * NM * 64 + i] = v;
+    if (m == 0 && lane < 32) {                               // 32 stats per tile: [half][e]
+        int hh = lane >> 4, e = lane & 15;
+        int dd = dtile * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+        uint2 o = {0u, 0u};
+        if (dd < g.Nd) {
+            FicDomStat st = pool_st[(size_t)plane * g.Nd_pad + dd];
+            o.x = st.sum;
+            o.y = __float_as_uint(st.s32 == 0.0f ? 0.0f : __fdiv_rn(1.0f, st.s32));
+        }
+        pool_sw[((size_t)plane * ndtiles_alloc + dtile) * 32 + lane] = o;
+    }
+}
+
+// range fragments + constants {K = 128*Sr - 16384*n, A = 128 - rM, negR = -rem, tau0}
+__global__ __launch_bounds__(256) void k_range_mfma1(const uint32_t* __restrict__ rng_pix, const FicRngStat* __restrict__ rng_st,
+                                                     v4i* __restrict__ rngB, int4* __restrict__ rconst, FicGeom g,
+                                                     int nctiles_alloc, int NM)
+{
+    int i = blockIdx.x * 256 + threadIdx.x;                  // (ctile, m, lane)
+    int plane = blockIdx.y;
+    if (i >= nctiles_alloc * NM * 64) return;
+    int lane = i & 63, m = (i >> 6) % NM, ctile = (i >> 6) / NM;
+    int j = ctile * 32 + (lane & 31), h = lane >> 5;
+    int off = 32 * m + 16 * h;
+    v4i v = {0, 0, 0, 0};
+    const bool in = j < g.Nr_pad;
+    if (in && off < g.n) {
+        const uint32_t* rp = rng_pix + (size_t)plane * g.Nr_pad * g.n_iso * g.DW;
+#pragma unroll
+        for (int w = 0; w < 4; w++) v[w] = (int)(rp[rng_word_index(g, j, 0, off / 4 + w)] ^ 0x80808080u);
+    }
+    rngB[(size_t)plane * nctiles_alloc * NM * 64 + i] = v;
+    if (m == 0 && lane < 32) {
+        int4 c = {0, 0, 0, 0};
+        if (in) {
+            FicRngStat st = rng_st[(size_t)plane * g.Nr_pad + j];
+            int Sr = st.rM * g.n + st.rem;
+            c.x = 128 * Sr - 16384 * g.n;
+            c.y = 128 - st.rM;
+            c.z = -st.rem;
+            c.w = (st.rem == 0) ? __float_as_int(8192.0f) : 0;   // rem == 0: nothing after the first block can win
+        }
+        rconst[(size_t)plane * nctiles_alloc * 32 + ctile * 32 + lane] = c;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // k_finalize : getBestDomainblock tail FC:634-642 + writeData quantiser FC:242-244.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_finalize(const uint32_t* __restrict__ pool_pix,
@@ -1308,6 +1487,41 @@ int fic_launch_sweep_mfma(const FicBuffers& b, const void* poolB, const void* rn
     A.ndtiles = ndtiles; A.ndtiles_alloc = ndtiles_alloc; A.ngroups = g.tiles;
     A.group0 = group0; A.tiles_per_chunk = tiles_per_chunk; A.nchunks = nchunks;
     hipLaunchKernelGGL(k_sweep_mfma, dim3(ngroups_launch, nchunks, g.planes), dim3(256), 0, s, A);
+    FIC_LAUNCH_CHECK();
+    return 0;
+}
+
+// opt-in matrix-core sweep, n_iso = 1 (B = 4 / 8 / 16): fragment prep + sweep
+int fic_mfma1_ct(int B) { return B == 4 ? 32 : B == 8 ? 16 : 4; }    // column tiles per workgroup (k_sweep_mfma1's CT)
+int fic_launch_mfma1_prep(const FicBuffers& b, void* poolA, void* pool_sw, void* rngB, void* rconst, const FicGeom& g,
+                          int ndtiles_alloc, int nctiles_alloc, hipStream_t s)
+{
+    const int NM = g.n <= 32 ? 1 : g.n / 32;
+    hipLaunchKernelGGL(k_pool_mfma1, dim3((ndtiles_alloc * NM * 64 + 255) / 256, g.planes), dim3(256), 0, s,
+                       (const uint8_t*)b.pool_pix, (const FicDomStat*)b.pool_st, (v4i*)poolA, (uint2*)pool_sw, g,
+                       ndtiles_alloc, NM);
+    FIC_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_range_mfma1, dim3((nctiles_alloc * NM * 64 + 255) / 256, g.planes), dim3(256), 0, s,
+                       (const uint32_t*)b.rng_pix, (const FicRngStat*)b.rng_st, (v4i*)rngB, (int4*)rconst, g,
+                       nctiles_alloc, NM);
+    FIC_LAUNCH_CHECK();
+    return 0;
+}
+int fic_launch_sweep_mfma1(const FicBuffers& b, const void* poolA, const void* pool_sw, const void* rngB,
+                           const void* rconst, const FicGeom& g, int ct_begin, int ct_end, int ndtiles, int ndtiles_alloc,
+                           int nctiles_alloc, int tiles_per_chunk, int nchunks, hipStream_t s)
+{
+    Mfma1Args A;
+    A.poolA = (const v4i*)poolA; A.pool_sw = (const uint2*)pool_sw; A.pool_st = b.pool_st; A.pool_s64 = b.pool_s64;
+    A.rngB = (const v4i*)rngB; A.rconst = (const int4*)rconst; A.key = b.key;
+    A.Nd = g.Nd; A.Nd_pad = g.Nd_pad; A.Nr = g.Nr; A.Nr_pad = g.Nr_pad; A.lgn = g.lgn;
+    A.ndtiles = ndtiles; A.ndtiles_alloc = ndtiles_alloc; A.nctiles_alloc = nctiles_alloc;
+    A.ct_begin = ct_begin; A.ct_end = ct_end; A.tiles_per_chunk = tiles_per_chunk; A.nchunks = nchunks;
+    const int CT = fic_mfma1_ct(g.B);
+    dim3 grid((ct_end - ct_begin + CT - 1) / CT, nchunks, g.planes), block(256);
+    if (g.B == 4) hipLaunchKernelGGL((k_sweep_mfma1<1>), grid, block, 0, s, A);
+    else if (g.B == 8) hipLaunchKernelGGL((k_sweep_mfma1<2>), grid, block, 0, s, A);
+    else hipLaunchKernelGGL((k_sweep_mfma1<8>), grid, block, 0, s, A);
     FIC_LAUNCH_CHECK();
     return 0;
 }

@@ -80,6 +80,12 @@ int fic_launch_sweep_mfma(const FicBuffers& b, const void* poolB, const void* rn
                           int group0, int ngroups_launch, int ndtiles, int ndtiles_alloc, int tiles_per_chunk, int nchunks,
                           hipStream_t s);
 
+int fic_mfma1_ct(int B);
+int fic_launch_mfma1_prep(const FicBuffers& b, void* poolA, void* pool_sw, void* rngB, void* rconst, const FicGeom& g,
+                          int ndtiles_alloc, int nctiles_alloc, hipStream_t s);
+int fic_launch_sweep_mfma1(const FicBuffers& b, const void* poolA, const void* pool_sw, const void* rngB,
+                           const void* rconst, const FicGeom& g, int ct_begin, int ct_end, int ndtiles, int ndtiles_alloc,
+                           int nctiles_alloc, int tiles_per_chunk, int nchunks, hipStream_t s);
 int fic_launch_decode_iteration_rgb(int32_t* scaled, int32_t* image, const int32_t* qrows5, FicDecodeState* state,
                                     int counter, const FicGeom& g, hipStream_t s);
 

@@ -78,6 +78,48 @@ def test_mfma_shards_and_1024():
 
 def test_mfma_is_refused_outside_its_configuration():
     with pytest.raises(fic_amd.FicError):
-        fic_amd.encode_gray(IMAGES["lena256"], 8, None, 1, sweep=3)
-    with pytest.raises(fic_amd.FicError):
         fic_amd.encode_gray(IMAGES["lena256"], 16, None, 8, sweep=3)
+    with pytest.raises(fic_amd.FicError):
+        fic_amd.encode_gray(IMAGES["lena256"], 4, None, 8, sweep=3)
+    with pytest.raises(fic_amd.FicError):
+        fic_amd.encode_gray(IMAGES["lena256"], 8, 16, 1, sweep=3)       # windowed search is not a sweep
+
+
+# ---- n_iso = 1: the reference algorithm on the matrix cores (k_sweep_mfma1, B = 4 / 8 / 16) -------------------
+
+ISO1 = [(n, B) for n in sorted(IMAGES) for B in (4, 8, 16)
+        if not (n in ("lena64", "flat64", "U200", "S200") and B == 16) and not (n in ("lena256", "S256", "U256") and B == 4)]
+
+
+@pytest.mark.parametrize("name,B", ISO1 + [("lena256", 4)])
+def test_mfma1_reference_algorithm_matches_oracle(oracle, name, B):
+    g = IMAGES[name]
+    h, w = g.shape
+    Dw = fic_amd.geometry(w, h, B)[2]
+    ref = oracle.encode_gray(oracle.gray_to_argb(g), w, h, B, Dw, 1)
+    for chunks in (0, 2):
+        got = fic_amd.encode_gray(g, B, None, 1, sweep=3, chunks=chunks)
+        assert (got["idx_local"] == ref["info"][:, 0].astype(np.int32)).all()
+        assert same_f32(got["a"], ref["info"][:, 1]) and same_f32(got["b"], ref["info"][:, 2])
+        assert (got["qrows"] == oracle.quantise_gray(ref["info"])).all()
+        assert same_f32(got["err"], ref["err"])
+
+
+@pytest.mark.parametrize("B,size", [(8, 1024), (4, 512), (16, 1024)])
+def test_mfma1_equals_valu_sweep_at_scale_and_sharded(B, size):
+    imgs = np.stack([synth.image_u(size, size, 31 + B), synth.image_s(size, size, 32 + B)])
+    with fic_amd.Encoder(size, size, B, None, 1, planes=2) as enc:
+        enc.set_gray(imgs)
+        enc.set_option("sweep", 2)
+        enc.encode()
+        valu = enc.results()
+        enc.set_option("sweep", 3)
+        spans = fic_amd.shard_spans(enc.n_ranges, enc.ranges_per_tile, 3)
+        parts = []
+        for b, c in spans:
+            enc.encode(b, c)
+            r = enc.results()
+            parts.append({k: v[:, b:b + c].copy() for k, v in r.items()})
+        assert enc.info()["sweep_kind"] == 3
+    cat = {k: np.concatenate([p[k] for p in parts], axis=1) for k in parts[0]}
+    _same(cat, valu)
