@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <mutex>
 #include <string>
@@ -355,7 +356,13 @@ int fic_ctx_encode(fic_ctx* c, int range_begin, int range_count, void* hip_strea
 
     // sweep
     int kind = c->opt_sweep;
-    if (kind == 0) kind = g.full ? 2 : 1;
+    if (kind == 0) {
+        kind = g.full ? 2 : 1;
+        // FIC_SWEEP=3 opts the whole process into the matrix-core sweep wherever it is built (same results);
+        // other geometries keep the VALU sweep.  An explicit fic_ctx_set_option("sweep", ...) wins.
+        const char* env = getenv("FIC_SWEEP");
+        if (env && env[0] == '3' && env[1] == '\0' && g.full && ((g.B == 8 && g.n_iso == 8) || g.n_iso == 1)) kind = 3;
+    }
     if (kind >= 2 && !g.full) return fail(FIC_E_ARGUMENT, "fast sweep needs full search (wK == Dw == Dh)");
     if (kind == 3 && !((g.B == 8 && g.n_iso == 8) || g.n_iso == 1))
         return fail(FIC_E_ARGUMENT, "the matrix-core sweep is built for n_iso = 1 (B = 4, 8, 16) and for B = 8, n_iso = 8");
