@@ -213,7 +213,8 @@ def main():
                       f"range-block matches/sec ({B}x{B} R, {2 * B}x{2 * B} D, {n_iso} iso)",
             "value": value, "unit": "range-block matches/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-            "scaling": scaling, "vs_baseline": None, "dtype": "u8 dot4 -> i32 (exact), f32/f64 epilogue",
+            "scaling": scaling, "vs_baseline": None, "dtype": "u8",
+            "dtype_detail": "u8 pixels, v_dot4_u32_u8 -> exact i32 covariances, f32 prune test, f64/f32 Java epilogue",
             "data": "synthetic",
             "config": {"workload": wl["desc"], "image": f"{W}x{H}", "B": B, "n_iso": n_iso, "wK": core.wK,
                        "planes_per_rank" if scaling == "weak" else "planes": planes,
@@ -236,7 +237,7 @@ def main():
             # opt-in matrix-core sweep: the inner products run on v_mfma_i32_32x32x32_i8 (dense i8 peak = 2x bf16
             # = 5.0 PetaOP/s, MI355X_MICROARCH.md "Matrix cores"); its VALU epilogue is ~3.5 instr per pair-eval.
             ops = pair_evals * 2.0 * n
-            out["dtype"] = "i8 MFMA -> i32 (exact), f32/f64 epilogue"
+            out["dtype_detail"] = "u8 pixels shifted to i8, v_mfma_i32_32x32x32_i8 -> exact i32 covariances, same epilogue"
             out["roofline_hbm_logical"] = dict(out["roofline"], kernel="k_sweep_mfma")
             out["roofline"] = {"bound": "mfma", "achieved": ops / (avg_ms * 1e-3) / 1e12, "peak": 5000.0,
                                "unit": "TOP/s", "frac": ops / (avg_ms * 1e-3) / 1e12 / 5000.0, "traffic": None,

@@ -411,3 +411,28 @@ def test_one_shot_context_cache_reuse(oracle):
                 assert (got["iso"] == ref["iso"]).all()
                 assert same_f32(got["a"], ref["info"][:, 1]) and same_f32(got["b"], ref["info"][:, 2])
     _c.release_cache()
+
+
+TINY = [  # w, h, B, wK, n_iso : minimum geometries (Rw or Rh = 2 -> Dw or Dh = 1; FC:534,539 branches when Rh == 2)
+    (16, 16, 8, 1, 1), (16, 16, 8, 1, 8), (8, 8, 4, 1, 1), (32, 32, 16, 1, 8),
+    (12, 12, 4, 1, 1), (12, 12, 4, 3, 1), (12, 12, 4, 3, 8), (24, 24, 8, 2, 1),
+    (32, 16, 8, 1, 1), (16, 32, 8, 1, 8), (48, 16, 8, 1, 1), (20, 8, 4, 1, 1), (64, 32, 16, 1, 1),
+]
+
+
+@pytest.mark.parametrize("w,h,B,wK,n_iso", TINY)
+def test_minimum_geometries(oracle, w, h, B, wK, n_iso):
+    g = synth.image_s(w, h, 1000 + w + h) if (w + h) % 3 else synth.image_u(w, h, 1000 + w + h)
+    ref = _oracle_encode(oracle, g, B, wK, n_iso)
+    Rw, Rh, Dw, Dh = fic_amd.geometry(w, h, B)
+    sweeps = [0, 1] + ([2] if wK == Dw == Dh else [])
+    if wK == Dw == Dh and (n_iso == 1 or B == 8):
+        sweeps.append(3)
+    for sweep in sweeps:
+        got = fic_amd.encode_gray(g, B, wK, n_iso, sweep=sweep)
+        _assert_same(oracle, got, ref)
+    run = fic_amd.write_run_gray(got["qrows"], w, h, B, wK)
+    if n_iso == 1:
+        want = oracle.decode_gray(run)
+        img, avg, it = fic_amd.decode_gray_run(run)
+        assert (img == want[0]).all() and it == want[2] and np.float32(avg).view(np.uint32) == np.float32(want[1]).view(np.uint32)
