@@ -1,6 +1,6 @@
 // FicNative.java -- the only Java a maintainer adds to the reference tree (same package):
-// the native binding of libfic_hip.so.  INTEGRATION.md shows the 10-line change in
-// FractalCompression.encodeGrayScale that calls it.  Not compiled in this image (no JDK).
+// the native binding of libfic_hip.so.  INTEGRATION.md shows the small changes in
+// FractalCompression that call it.  Not compiled in this image (no JDK).
 package bvk_ss19;
 
 public final class FicNative {
@@ -25,4 +25,23 @@ public final class FicNative {
      */
     public static native void encodeGray(int[] argb, int width, int height, int blockgroesse, int widthKernel,
                                          int device, float[] out3N, int[] quant3N);
+
+    /**
+     * Replaces the search of encodeRGB, FractalCompression.java:181-215.
+     *
+     * @param out5N  float[N_r*5] receiving imageInfoRGB rows {i_local, a, bR, bG, bB} (FractalCompression.java:185,212)
+     */
+    public static native void encodeRgb(int[] argb, int width, int height, int blockgroesse, int widthKernel,
+                                        int device, float[] out5N);
+
+    /**
+     * decodeGreyScale / decodeRGB (FractalCompression.java:356-421 / 430-508) on a complete .run stream,
+     * INCLUDING the leading isRGB int that FractalCompression.decode consumed (FractalCompression.java:548).
+     *
+     * @param run       the stream bytes
+     * @param avgError  float[1]: in = FractalCompression.avgError before the call (the static is never reset),
+     *                  out = its value afterwards
+     * @return int[2 + w*h]: {width, height, argb...} of the decoded image
+     */
+    public static native int[] decode(byte[] run, int device, float[] avgError);
 }

@@ -11,6 +11,8 @@
 // becomes a thrown std::runtime_error carrying fic_last_error().
 #pragma once
 #include <cstdint>
+#include <istream>
+#include <iterator>
 #include <ostream>
 #include <stdexcept>
 #include <string>
@@ -40,11 +42,56 @@ public:
         return check(fic_is_greyscale_argb(input.argb.data(), input.width, input.height)) == 1;
     }
 
+    static inline float avgError = 0.0f;         // FractalCompression.java:20 -- never reset between decode calls
+    static float getAvgError() { return avgError; }   // FractalCompression.java:22-24
+
     // FractalCompression.java:54-59.  Returns the collage image like the reference.
     static RasterImage encode(const RasterImage& input, std::ostream& out)
     {
         if (isGreyScale(input)) return encodeGrayScale(input, out);
-        throw std::runtime_error("encodeRGB (FractalCompression.java:171) is not GPU-backed yet");
+        return encodeRGB(input, out);
+    }
+
+    // FractalCompression.java:171-219: joint-RGB search on the GPU, writeData(out, 1, ...), RGB collage back.
+    static RasterImage encodeRGB(const RasterImage& input, std::ostream& out)
+    {
+        int Rw = 0, Rh = 0;
+        check(fic_geometry(input.width, input.height, blockgroesse, &Rw, &Rh, nullptr, nullptr));
+        const int nr = Rw * Rh;
+        std::vector<int32_t> idx(nr), q((size_t)nr * 5);
+        std::vector<float> a(nr), bR(nr), bG(nr), bB(nr);
+        RasterImage collage(input.width, input.height);
+        check(fic_encode_rgb_argb(input.argb.data(), input.width, input.height, blockgroesse, widthKernel, device, idx.data(),
+                                  a.data(), bR.data(), bG.data(), bB.data(), q.data(), collage.argb.data()));
+        std::vector<uint8_t> buf(20 + 4 * q.size());
+        int64_t n = fic_write_run_rgb(q.data(), nr, input.width, input.height, blockgroesse, widthKernel, buf.data(),
+                                      (int64_t)buf.size());
+        if (n < 0) throw std::runtime_error(fic_last_error());
+        out.write(reinterpret_cast<const char*>(buf.data()), n);
+        out.flush();
+        return collage;
+    }
+
+    // FractalCompression.java:547-553: reads the whole .run stream and dispatches on its first int.
+    static RasterImage decode(std::istream& in)
+    {
+        std::vector<uint8_t> run((std::istreambuf_iterator<char>(in)), std::istreambuf_iterator<char>());
+        if (run.size() < 20) throw std::runtime_error("decode: stream shorter than its header (EOFException)");
+        const bool rgb = (run[0] | run[1] | run[2] | run[3]) != 0;
+        int w = 0, h = 0;
+        auto be = [&](size_t o) { return (int)((run[o] << 24) | (run[o + 1] << 16) | (run[o + 2] << 8) | run[o + 3]); };
+        RasterImage img(be(4) > 0 ? be(4) : 0, be(8) > 0 ? be(8) : 0);
+        if (rgb) {
+            check(fic_decode_rgb_run(run.data(), (int64_t)run.size(), device, img.argb.data(), (int64_t)img.argb.size(), &w, &h,
+                                     &avgError, nullptr));
+        } else {
+            std::vector<uint8_t> g(img.argb.size());
+            check(fic_decode_gray_run(run.data(), (int64_t)run.size(), device, g.data(), (int64_t)g.size(), &w, &h, &avgError,
+                                      nullptr));
+            for (size_t i = 0; i < g.size(); i++)
+                img.argb[i] = (int32_t)(0xff000000u | ((uint32_t)g[i] << 16) | ((uint32_t)g[i] << 8) | g[i]);
+        }
+        return img;
     }
 
     // FractalCompression.java:109-162: search on the GPU, writeData to `out`, collage back.

@@ -1,34 +1,59 @@
 // Drives the C++ host mirror (include/fic_host.hpp) the way RLEAppController.openDecodedImage
-// (RLEAppController.java:172-188) drives the reference: set the two statics, call encode(image, out).
-// Usage: host_mirror_test <gray.raw> <w> <h> <B> <wK> <out.run> <collage.raw>
+// (RLEAppController.java:172-188) drives the reference: set the two statics, encode(image, out), decode(in).
+//   host_mirror_test encode      <gray.raw u8>   w h B wK out.run collage.raw
+//   host_mirror_test encode_argb <argb.raw i32>  w h B wK out.run collage.raw     (colour -> encodeRGB)
+//   host_mirror_test decode      <in.run> out_argb.raw                            (prints avgError)
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <fstream>
 #include <iostream>
 #include "fic_host.hpp"
 
+using FC = bvk_ss19::FractalCompression;
+
+static int run(int argc, char** argv)
+{
+    if (argc >= 4 && !std::strcmp(argv[1], "decode")) {
+        std::ifstream in(argv[2], std::ios::binary);
+        bvk_ss19::RasterImage img = FC::decode(in);
+        std::ofstream o(argv[3], std::ios::binary);
+        o.write(reinterpret_cast<const char*>(img.argb.data()), (std::streamsize)(img.argb.size() * 4));
+        std::printf("%d %d %.9g\n", img.width, img.height, (double)FC::getAvgError());
+        return 0;
+    }
+    if (argc != 9 || (std::strcmp(argv[1], "encode") && std::strcmp(argv[1], "encode_argb"))) {
+        std::fprintf(stderr, "usage: %s encode|encode_argb in.raw w h B wK out.run collage.raw | decode in.run out.raw\n", argv[0]);
+        return 2;
+    }
+    const bool argb = !std::strcmp(argv[1], "encode_argb");
+    int w = std::atoi(argv[3]), h = std::atoi(argv[4]);
+    bvk_ss19::RasterImage img(w, h);
+    std::ifstream in(argv[2], std::ios::binary);
+    if (argb) {
+        in.read(reinterpret_cast<char*>(img.argb.data()), (std::streamsize)(img.argb.size() * 4));
+    } else {
+        std::vector<unsigned char> g((size_t)w * h);
+        in.read(reinterpret_cast<char*>(g.data()), (std::streamsize)g.size());
+        for (size_t i = 0; i < g.size(); i++)
+            img.argb[i] = (int32_t)(0xff000000u | ((uint32_t)g[i] << 16) | ((uint32_t)g[i] << 8) | g[i]);
+    }
+    if (!in) { std::fprintf(stderr, "short read\n"); return 2; }
+    FC::blockgroesse = std::atoi(argv[5]);
+    FC::widthKernel = std::atoi(argv[6]);
+    std::ofstream out(argv[7], std::ios::binary);
+    bvk_ss19::RasterImage collage = FC::encode(img, out);
+    std::ofstream c(argv[8], std::ios::binary);
+    c.write(reinterpret_cast<const char*>(collage.argb.data()), (std::streamsize)(collage.argb.size() * 4));
+    return 0;
+}
+
 int main(int argc, char** argv)
 {
-    if (argc != 8) { std::fprintf(stderr, "usage: %s gray.raw w h B wK out.run collage.raw\n", argv[0]); return 2; }
-    int w = std::atoi(argv[2]), h = std::atoi(argv[3]);
-    std::vector<unsigned char> g((size_t)w * h);
-    std::ifstream in(argv[1], std::ios::binary);
-    in.read(reinterpret_cast<char*>(g.data()), (std::streamsize)g.size());
-    if (!in) { std::fprintf(stderr, "short read\n"); return 2; }
-    bvk_ss19::RasterImage img(w, h);
-    for (size_t i = 0; i < g.size(); i++)
-        img.argb[i] = (int32_t)(0xff000000u | ((uint32_t)g[i] << 16) | ((uint32_t)g[i] << 8) | g[i]);
-    using FC = bvk_ss19::FractalCompression;
-    FC::blockgroesse = std::atoi(argv[4]);
-    FC::widthKernel = std::atoi(argv[5]);
     try {
-        std::ofstream out(argv[6], std::ios::binary);
-        bvk_ss19::RasterImage collage = FC::encode(img, out);
-        std::ofstream c(argv[7], std::ios::binary);
-        c.write(reinterpret_cast<const char*>(collage.argb.data()), (std::streamsize)(collage.argb.size() * 4));
+        return run(argc, argv);
     } catch (const std::exception& e) {
         std::fprintf(stderr, "exception: %s\n", e.what());
         return 1;
     }
-    return 0;
 }

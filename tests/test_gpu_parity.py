@@ -296,8 +296,8 @@ def test_iso8_never_worse_than_iso1_and_decodes(oracle):
 
 
 def test_cpp_host_mirror_of_the_java_entry_point(oracle, tmp_path):
-    """include/fic_host.hpp: bvk_ss19::FractalCompression::encode(RasterImage, ostream) driven like
-    RLEAppController.openDecodedImage (CTL:172-188) -- .run bytes and collage equal the oracle's."""
+    """include/fic_host.hpp: bvk_ss19::FractalCompression::encode(RasterImage, ostream) / decode(istream) driven
+    like RLEAppController.openDecodedImage (CTL:172-188) -- .run bytes, collage and decoded image equal the oracle's."""
     import subprocess
     exe = os.path.join(os.path.dirname(GOLDEN), "cpp", "host_mirror_test")
     if not os.path.exists(exe):
@@ -307,13 +307,29 @@ def test_cpp_host_mirror_of_the_java_entry_point(oracle, tmp_path):
     raw.write_bytes(g.tobytes())
     for B, wK in [(8, 2), (8, 61), (4, 16)]:
         run, col = tmp_path / f"o{B}_{wK}.run", tmp_path / f"c{B}_{wK}.raw"
-        subprocess.check_call([exe, str(raw), "256", "256", str(B), str(wK), str(run), str(col)])
+        subprocess.check_call([exe, "encode", str(raw), "256", "256", str(B), str(wK), str(run), str(col)])
         ref = _oracle_encode(oracle, g, B, wK, 1)
         assert run.read_bytes() == oracle.write_run_gray(ref["info"], 256, 256, B, wK)
         want = oracle.collage_gray(oracle.gray_to_argb(g), 256, 256, B, wK, ref["info"])
         assert (np.frombuffer(col.read_bytes(), np.int32) == want).all()
+        dec = tmp_path / "d.raw"
+        out = subprocess.check_output([exe, "decode", str(run), str(dec)], text=True).split()
+        wimg, wavg, _ = oracle.decode_gray(run.read_bytes())
+        got = (np.frombuffer(dec.read_bytes(), np.int32).view(np.uint32) >> 16) & 0xFF
+        assert (got.reshape(256, 256) == wimg).all() and np.float32(out[2]) == wavg
+    # colour input dispatches to encodeRGB: the reference's own unknown.run comes out, and decodes back
+    c = np.load(os.path.join(GOLDEN, "lena_colored_256.npy"))
+    argb = oracle.rgb_to_argb(c)
+    araw, run, col, dec = tmp_path / "a.raw", tmp_path / "k1.run", tmp_path / "k1c.raw", tmp_path / "k1d.raw"
+    araw.write_bytes(argb.tobytes())
+    subprocess.check_call([exe, "encode_argb", str(araw), "256", "256", "8", "2", str(run), str(col)])
+    assert run.read_bytes() == open(os.path.join(GOLDEN, "unknown_run.bin"), "rb").read()
+    subprocess.check_call([exe, "decode", str(run), str(dec)], stdout=subprocess.DEVNULL)
+    wrgb, _, _ = oracle.decode_rgb(run.read_bytes())
+    u = np.frombuffer(dec.read_bytes(), np.int32).view(np.uint32)
+    assert (np.stack([(u >> 16) & 0xFF, (u >> 8) & 0xFF, u & 0xFF], -1).reshape(256, 256, 3) == wrgb).all()
     # bad geometry -> exception (exit code 1), like the reference's unchecked exceptions
-    rc = subprocess.call([exe, str(raw), "256", "256", "8", "200", str(tmp_path / "x.run"), str(tmp_path / "x.raw")],
+    rc = subprocess.call([exe, "encode", str(raw), "256", "256", "8", "200", str(tmp_path / "x.run"), str(tmp_path / "x.raw")],
                          stderr=subprocess.DEVNULL)
     assert rc == 1
 
