@@ -452,3 +452,62 @@ def test_minimum_geometries(oracle, w, h, B, wK, n_iso):
         want = oracle.decode_gray(run)
         img, avg, it = fic_amd.decode_gray_run(run)
         assert (img == want[0]).all() and it == want[2] and np.float32(avg).view(np.uint32) == np.float32(want[1]).view(np.uint32)
+
+
+def test_seeded_fuzz_geometries_windows_sweeps(oracle):
+    """60 random (W, H, B, wK, n_iso, image kind) cases, every applicable sweep kernel, against the oracle."""
+    rng = np.random.default_rng(20261004)
+    done = 0
+    while done < 60:
+        B = int(rng.choice([4, 8, 16]))
+        Rw, Rh = int(rng.integers(2, 160 // B + 1)), int(rng.integers(2, 160 // B + 1))
+        w, h = Rw * B, Rh * B
+        Dw, Dh = 2 * Rw - 3, 2 * Rh - 3
+        square_full = (Dw == Dh) and rng.random() < 0.5
+        wK = Dw if square_full else int(rng.integers(1, min(Dw, Dh, 17) + 1))
+        n_iso = int(rng.choice([1, 8]))
+        kind = rng.choice(["U", "S", "flat", "ramp"])
+        seed = int(rng.integers(1, 1 << 30))
+        if kind == "U":
+            g = synth.image_u(w, h, seed)
+        elif kind == "S":
+            g = synth.image_s(w, h, seed)
+        elif kind == "flat":
+            g = np.full((h, w), seed % 256, np.uint8)
+        else:
+            g = ((np.arange(w)[None, :] * 3 + np.arange(h)[:, None] * 5 + seed) % 256).astype(np.uint8)
+        ref = oracle.encode_gray(oracle.gray_to_argb(g), w, h, B, wK, n_iso)
+        sweeps = [1]
+        if wK == Dw == Dh:
+            sweeps.append(2)
+            if n_iso == 1 or B == 8:
+                sweeps.append(3)
+        for sweep in sweeps:
+            got = fic_amd.encode_gray(g, B, wK, n_iso, sweep=sweep, chunks=int(rng.integers(0, 4)) if sweep >= 2 else 0)
+            try:
+                _assert_same(oracle, got, ref)
+            except AssertionError as e:
+                raise AssertionError(f"case w={w} h={h} B={B} wK={wK} n_iso={n_iso} kind={kind} seed={seed} sweep={sweep}: {e}")
+        done += 1
+
+
+def test_concurrent_one_shot_calls_from_threads(oracle):
+    """Several host threads encode different images/geometries at once through the one-shot C entry point."""
+    from concurrent.futures import ThreadPoolExecutor
+    from fic_amd import capi as _c
+    jobs = [("lena256", 8, 2, 1), ("S256", 8, None, 8), ("U256", 16, None, 1), ("lena256", 4, 16, 1),
+            ("S256", 16, 8, 8), ("U256", 8, None, 1)] * 3
+
+    def work(job):
+        name, B, wK, n_iso = job
+        return job, _c.encode_gray_oneshot(IMAGES[name], B, wK, n_iso)
+
+    with ThreadPoolExecutor(6) as ex:
+        results = list(ex.map(work, jobs))
+    for (name, B, wK, n_iso), got in results:
+        Dw = fic_amd.geometry(256, 256, B)[2]
+        ref = _oracle_encode(oracle, IMAGES[name], B, Dw if wK is None else wK, n_iso)
+        assert (got["idx_local"] == ref["info"][:, 0].astype(np.int32)).all()
+        assert (got["iso"] == ref["iso"]).all()
+        assert same_f32(got["a"], ref["info"][:, 1]) and same_f32(got["b"], ref["info"][:, 2])
+    _c.release_cache()
