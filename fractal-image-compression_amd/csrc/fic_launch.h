@@ -1,4 +1,5 @@
-// fic_launch.h -- internal: device buffer bundle + kernel launchers (fic_kernels.hip).
+// fic_launch.h -- internal: device buffer bundles + the kernel launchers of fic_prep / fic_sweep / fic_mfma /
+// fic_decode / fic_rgb .hip, as called by fic_capi.cpp.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -90,5 +91,6 @@ int fic_launch_decode_iteration_rgb(int32_t* scaled, int32_t* image, const int32
                                     int counter, const FicGeom& g, hipStream_t s);
 
 // decoder (FC:356-421)
+int fic_launch_decode_step(FicDecodeState* state, int counter, int wh, int planes, hipStream_t s);
 int fic_launch_decode_iteration(uint8_t* scaled, uint8_t* image, const int32_t* qrows, const int32_t* iso,
                                 FicDecodeState* state, int counter, const FicGeom& g, hipStream_t s);
