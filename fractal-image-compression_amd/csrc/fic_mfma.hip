@@ -103,9 +103,10 @@ __global__ __launch_bounds__(256) void k_sweep_mfma(MfmaArgs A)
                                                                      // range 4t+q belongs to the wave that owns row tile t
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int group = A.group0 + blockIdx.x;
-    const int plane = blockIdx.z;
-    const int chunk = blockIdx.y;                      // all 4 waves sweep the same pool chunk (B tiles hit in L1) ...
+    // XCD-aware mapping as in k_sweep_fast: fastest grid dimension = (pool chunk, plane), slow one = range group
+    const int group = A.group0 + blockIdx.y;
+    const int plane = blockIdx.x / A.nchunks;
+    const int chunk = blockIdx.x % A.nchunks;                      // all 4 waves sweep the same pool chunk (B tiles hit in L1) ...
     const int t_first = wave * (RT / 4);               // ... and split the 16 row tiles
     const size_t gbase = (size_t)plane * A.ngroups + group;
     const AS4 int* rc_base = (const AS4 int*)A.rconst + gbase * RT * 16;
@@ -232,13 +233,13 @@ __global__ __launch_bounds__(256) void k_sweep_mfma1(Mfma1Args A)
     __shared__ int4 sC[CT * 32];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int plane = blockIdx.z;
-    const int ct0 = A.ct_begin + blockIdx.x * CT;            // first column tile of the workgroup
+    const int plane = blockIdx.x / A.nchunks;               // XCD-aware mapping: (pool chunk, plane) fastest
+    const int ct0 = A.ct_begin + blockIdx.y * CT;            // first column tile of the workgroup
     const size_t cbase = (size_t)plane * A.nctiles_alloc + ct0;
     for (int i = threadIdx.x; i < CT * NM * 64; i += 256) sB[i] = A.rngB[cbase * NM * 64 + i];
     for (int i = threadIdx.x; i < CT * 32; i += 256) sC[i] = A.rconst[cbase * 32 + i];
     __syncthreads();
-    const int chunk = blockIdx.y;
+    const int chunk = blockIdx.x % A.nchunks;
     const int dt0 = chunk * A.tiles_per_chunk;
     int dt1 = dt0 + A.tiles_per_chunk;
     if (dt1 > A.ndtiles) dt1 = A.ndtiles;
@@ -402,7 +403,7 @@ int fic_launch_sweep_mfma(const FicBuffers& b, const void* poolB, const void* rn
     A.Nd = g.Nd; A.Nd_pad = g.Nd_pad; A.Nr_pad = g.Nr_pad; A.lgn = g.lgn;
     A.ndtiles = ndtiles; A.ndtiles_alloc = ndtiles_alloc; A.ngroups = g.tiles;
     A.group0 = group0; A.tiles_per_chunk = tiles_per_chunk; A.nchunks = nchunks;
-    hipLaunchKernelGGL(k_sweep_mfma, dim3(ngroups_launch, nchunks, g.planes), dim3(256), 0, s, A);
+    hipLaunchKernelGGL(k_sweep_mfma, dim3(nchunks * g.planes, ngroups_launch, 1), dim3(256), 0, s, A);
     FIC_LAUNCH_CHECK();
     return 0;
 }
@@ -436,7 +437,7 @@ int fic_launch_sweep_mfma1(const FicBuffers& b, const void* poolA, const void* p
     A.ndtiles = ndtiles; A.ndtiles_alloc = ndtiles_alloc; A.nctiles_alloc = nctiles_alloc;
     A.ct_begin = ct_begin; A.ct_end = ct_end; A.tiles_per_chunk = tiles_per_chunk; A.nchunks = nchunks;
     const int CT = fic_mfma1_ct(g.B);
-    dim3 grid((ct_end - ct_begin + CT - 1) / CT, nchunks, g.planes), block(256);
+    dim3 grid(nchunks * g.planes, (ct_end - ct_begin + CT - 1) / CT, 1), block(256);
     if (g.B == 4) hipLaunchKernelGGL((k_sweep_mfma1<1>), grid, block, 0, s, A);
     else if (g.B == 8) hipLaunchKernelGGL((k_sweep_mfma1<2>), grid, block, 0, s, A);
     else hipLaunchKernelGGL((k_sweep_mfma1<8>), grid, block, 0, s, A);
