@@ -79,6 +79,7 @@ def cpu_baseline(wl, img, budget_s=12.0):
     try:
         from concurrent.futures import ThreadPoolExecutor
         cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        cores = min(cores, 16)          # a 1-GPU box's CPU share on this pool
         per = max(2, min(Rw * Rh // cores, int(0.5 * budget_s / per_range)))
         t0 = time.perf_counter()
         with ThreadPoolExecutor(cores) as ex:

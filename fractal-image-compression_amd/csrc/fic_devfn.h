@@ -120,6 +120,25 @@ __device__ __forceinline__ size_t rng_word_index(const FicGeom& g, int j, int k,
     return ((((size_t)tile * g.NR + rs) * g.n_iso + k) * g.DW + dw) * 64 + lane;
 }
 
+// XCD-aware decode of a 1-D grid of ncombos x ntg workgroups.  The dispatcher deals workgroups round-robin over
+// the 8 XCDs by linear id (MI355X_MICROARCH.md "Workgroup dispatch"), so inside every window of 8*ntg consecutive
+// ids, id % 8 selects one of 8 "combos" (a pool chunk of a plane: the data the workgroups share through L2) and
+// id / 8 the range-tile group x: all ntg workgroups of a combo land on ONE XCD and are dispatched together, so
+// they stream the chunk in lock-step out of that XCD's L2.  Placement only affects speed, never results.
+__device__ __forceinline__ void xcd_decode(unsigned p, int ncombos, int ntg, int& combo, int& x)
+{
+    const unsigned full = (unsigned)(ncombos / 8) * 8u * (unsigned)ntg;
+    if (p < full) {
+        const unsigned r = p >> 3;
+        combo = (int)((r / (unsigned)ntg) * 8u + (p & 7u));
+        x = (int)(r % (unsigned)ntg);
+    } else {                                   // the last ncombos % 8 combos: plain order
+        const unsigned q = p - full;
+        combo = (ncombos / 8) * 8 + (int)(q / (unsigned)ntg);
+        x = (int)(q % (unsigned)ntg);
+    }
+}
+
 // host-side: surface a failed kernel launch to the C ABI
 #define FIC_LAUNCH_CHECK()                         \
     do {                                           \

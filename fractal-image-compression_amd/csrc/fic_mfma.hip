@@ -91,8 +91,8 @@ struct MfmaArgs {
     unsigned long long* key;
     int Nd, Nd_pad, Nr_pad, lgn;
     int ndtiles, ndtiles_alloc, ngroups;
-    int group0;                      // first range group of this shard
-    int tiles_per_chunk, nchunks;
+    int group0, ngroups_launch;      // first range group of this shard, groups in this launch
+    int tiles_per_chunk, nchunks, planes;
 };
 
 __global__ __launch_bounds__(256) void k_sweep_mfma(MfmaArgs A)
@@ -103,10 +103,11 @@ __global__ __launch_bounds__(256) void k_sweep_mfma(MfmaArgs A)
                                                                      // range 4t+q belongs to the wave that owns row tile t
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    // XCD-aware mapping as in k_sweep_fast: fastest grid dimension = (pool chunk, plane), slow one = range group
-    const int group = A.group0 + blockIdx.y;
-    const int plane = blockIdx.x / A.nchunks;
-    const int chunk = blockIdx.x % A.nchunks;                      // all 4 waves sweep the same pool chunk (B tiles hit in L1) ...
+    int combo_, gx_;                                   // XCD-aware 1-D grid: combo = (pool chunk, plane), x = range group
+    xcd_decode(blockIdx.x, A.nchunks * A.planes, A.ngroups_launch, combo_, gx_);
+    const int group = A.group0 + gx_;
+    const int plane = combo_ / A.nchunks;
+    const int chunk = combo_ % A.nchunks;                      // all 4 waves sweep the same pool chunk (B tiles hit in L1) ...
     const int t_first = wave * (RT / 4);               // ... and split the 16 row tiles
     const size_t gbase = (size_t)plane * A.ngroups + group;
     const AS4 int* rc_base = (const AS4 int*)A.rconst + gbase * RT * 16;
@@ -221,7 +222,8 @@ struct Mfma1Args {
     int Nd, Nd_pad, Nr, Nr_pad, lgn;
     int ndtiles, ndtiles_alloc, nctiles_alloc;
     int ct_begin, ct_end;            // column tiles (x32 ranges) of this shard
-    int tiles_per_chunk, nchunks;
+    int nctg;                        // column-tile groups (workgroups) in this launch
+    int tiles_per_chunk, nchunks, planes;
 };
 
 template <int NM>
@@ -233,13 +235,15 @@ __global__ __launch_bounds__(256) void k_sweep_mfma1(Mfma1Args A)
     __shared__ int4 sC[CT * 32];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int plane = blockIdx.x / A.nchunks;               // XCD-aware mapping: (pool chunk, plane) fastest
-    const int ct0 = A.ct_begin + blockIdx.y * CT;            // first column tile of the workgroup
+    int combo_, gx_;                                         // XCD-aware 1-D grid: combo = (pool chunk, plane)
+    xcd_decode(blockIdx.x, A.nchunks * A.planes, A.nctg, combo_, gx_);
+    const int plane = combo_ / A.nchunks;
+    const int ct0 = A.ct_begin + gx_ * CT;            // first column tile of the workgroup
     const size_t cbase = (size_t)plane * A.nctiles_alloc + ct0;
     for (int i = threadIdx.x; i < CT * NM * 64; i += 256) sB[i] = A.rngB[cbase * NM * 64 + i];
     for (int i = threadIdx.x; i < CT * 32; i += 256) sC[i] = A.rconst[cbase * 32 + i];
     __syncthreads();
-    const int chunk = blockIdx.x % A.nchunks;
+    const int chunk = combo_ % A.nchunks;
     const int dt0 = chunk * A.tiles_per_chunk;
     int dt1 = dt0 + A.tiles_per_chunk;
     if (dt1 > A.ndtiles) dt1 = A.ndtiles;
@@ -402,8 +406,9 @@ int fic_launch_sweep_mfma(const FicBuffers& b, const void* poolB, const void* rn
     A.rngA = (const v4i*)rngA; A.rconst = rconst; A.key = b.key;
     A.Nd = g.Nd; A.Nd_pad = g.Nd_pad; A.Nr_pad = g.Nr_pad; A.lgn = g.lgn;
     A.ndtiles = ndtiles; A.ndtiles_alloc = ndtiles_alloc; A.ngroups = g.tiles;
-    A.group0 = group0; A.tiles_per_chunk = tiles_per_chunk; A.nchunks = nchunks;
-    hipLaunchKernelGGL(k_sweep_mfma, dim3(nchunks * g.planes, ngroups_launch, 1), dim3(256), 0, s, A);
+    A.group0 = group0; A.ngroups_launch = ngroups_launch; A.tiles_per_chunk = tiles_per_chunk; A.nchunks = nchunks;
+    A.planes = g.planes;
+    hipLaunchKernelGGL(k_sweep_mfma, dim3((unsigned)(nchunks * g.planes) * (unsigned)ngroups_launch), dim3(256), 0, s, A);
     FIC_LAUNCH_CHECK();
     return 0;
 }
@@ -437,7 +442,9 @@ int fic_launch_sweep_mfma1(const FicBuffers& b, const void* poolA, const void* p
     A.ndtiles = ndtiles; A.ndtiles_alloc = ndtiles_alloc; A.nctiles_alloc = nctiles_alloc;
     A.ct_begin = ct_begin; A.ct_end = ct_end; A.tiles_per_chunk = tiles_per_chunk; A.nchunks = nchunks;
     const int CT = fic_mfma1_ct(g.B);
-    dim3 grid(nchunks * g.planes, (ct_end - ct_begin + CT - 1) / CT, 1), block(256);
+    A.nctg = (ct_end - ct_begin + CT - 1) / CT;
+    A.planes = g.planes;
+    dim3 grid((unsigned)(nchunks * g.planes) * (unsigned)A.nctg), block(256);
     if (g.B == 4) hipLaunchKernelGGL((k_sweep_mfma1<1>), grid, block, 0, s, A);
     else if (g.B == 8) hipLaunchKernelGGL((k_sweep_mfma1<2>), grid, block, 0, s, A);
     else hipLaunchKernelGGL((k_sweep_mfma1<8>), grid, block, 0, s, A);

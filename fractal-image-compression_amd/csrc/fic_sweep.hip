@@ -90,6 +90,7 @@ struct SweepArgs {
     int Nd, Nd_pad, Nr, Nr_pad, n_iso, lgn;
     int tile0, ntiles;         // tiles [tile0, tile0+ntiles) of 64*NR ranges
     int chunk_len, nchunks;    // domain chunk length (multiple of 2), number of chunks
+    int planes;
 };
 
 template <int DW, int NR, int NC>
@@ -101,12 +102,11 @@ __global__ __launch_bounds__(256) void k_sweep_fast(SweepArgs A)
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    // XCD-aware mapping: workgroups are dealt round-robin over the 8 XCDs by linear block id, so the fastest grid
-    // dimension carries (pool chunk x isometry group, plane) and the slow one the range-tile group: every workgroup
-    // that streams a given plane's pool chunk lands on the same XCD and its L2 caches 1/8 of the pools instead of
-    // all of them (measured: -0.5 % cfg2, -0.8 % cfg4 -- the sweep is VALU-bound, so the win is small).
+    // XCD-aware 1-D grid (xcd_decode, fic_devfn.h): combo = (pool chunk x isometry group, plane), x = range-tile group
     const int gy_ = A.nchunks * (A.n_iso / NC);
-    const int bx_ = blockIdx.y, by_ = blockIdx.x % gy_, bz_ = blockIdx.x / gy_;
+    int combo_, bx_;
+    xcd_decode(blockIdx.x, gy_ * A.planes, (A.ntiles + 3) / 4, combo_, bx_);
+    const int by_ = combo_ % gy_, bz_ = combo_ / gy_;
     const int tl = bx_ * 4 + wave;
     if (tl >= A.ntiles) return;                        // wave-uniform
     const int tile = A.tile0 + tl;
@@ -343,11 +343,10 @@ int fic_launch_sweep_fast(const FicBuffers& b, const FicGeom& g, int tile0, int 
     A.rng_st = b.rng_st;
     A.key = b.key;
     A.Nd = g.Nd; A.Nd_pad = g.Nd_pad; A.Nr = g.Nr; A.Nr_pad = g.Nr_pad; A.n_iso = g.n_iso; A.lgn = g.lgn;
-    A.tile0 = tile0; A.ntiles = ntiles; A.chunk_len = chunk_len; A.nchunks = nchunks;
+    A.tile0 = tile0; A.ntiles = ntiles; A.chunk_len = chunk_len; A.nchunks = nchunks; A.planes = g.planes;
     int NR, NC;
     if (fic_fast_variant(g.B, g.n_iso, &NR, &NC) || NR != g.NR) return -1;
-    if ((ntiles + 3) / 4 > 65535) return -1;                       // grid.y limit (an image beyond ~16k x 16k at B = 4)
-    dim3 grid(nchunks * (g.n_iso / NC) * g.planes, (ntiles + 3) / 4, 1);
+    dim3 grid((unsigned)(nchunks * (g.n_iso / NC) * g.planes) * (unsigned)((ntiles + 3) / 4), 1, 1);
     dim3 block(256);
     if (g.B == 4 && g.n_iso == 1) hipLaunchKernelGGL((k_sweep_fast<4, 4, 1>), grid, block, 0, s, A);
     else if (g.B == 4) hipLaunchKernelGGL((k_sweep_fast<4, 1, 8>), grid, block, 0, s, A);
