@@ -511,3 +511,27 @@ def test_concurrent_one_shot_calls_from_threads(oracle):
         assert (got["iso"] == ref["iso"]).all()
         assert same_f32(got["a"], ref["info"][:, 1]) and same_f32(got["b"], ref["info"][:, 2])
     _c.release_cache()
+
+
+def _near_tie_image(w, h, seed, density):
+    """A 16x16 base tile repeated over the image + sparse +-1 perturbations: thousands of almost identical
+    domain blocks (near-ties of |cov|/sqrt(var) at the 1e-3..1e-6 level) and many exactly identical ones."""
+    rng = np.random.default_rng(seed)
+    tile = rng.integers(40, 216, (16, 16))
+    img = np.tile(tile, (h // 16 + 1, w // 16 + 1))[:h, :w].astype(np.int32)
+    mask = rng.random((h, w)) < density
+    img = img + mask * rng.choice([-1, 1], (h, w))
+    return np.clip(img, 0, 255).astype(np.uint8)
+
+
+@pytest.mark.parametrize("B,n_iso", [(8, 1), (8, 8), (4, 1), (16, 1), (16, 8), (4, 8)])
+@pytest.mark.parametrize("density", [0.0, 0.002, 0.02])
+def test_near_tie_images(oracle, B, n_iso, density):
+    g = _near_tie_image(128, 128, 7 + B + n_iso, density)
+    Dw = fic_amd.geometry(128, 128, B)[2]
+    ref = _oracle_encode(oracle, g, B, Dw, n_iso)
+    sweeps = [2, 1] + ([3] if (n_iso == 1 or B == 8) else [])
+    for sweep in sweeps:
+        for chunks in ((0, 3) if sweep >= 2 else (0,)):
+            got = fic_amd.encode_gray(g, B, None, n_iso, sweep=sweep, chunks=chunks)
+            _assert_same(oracle, got, ref)
