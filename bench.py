@@ -100,6 +100,8 @@ def main():
     ap.add_argument("--scaling", default=None, choices=["weak", "strong"])
     ap.add_argument("--planes", type=int, default=None, help="override images per GPU (weak) / total (strong)")
     ap.add_argument("--n-iso", type=int, default=None, choices=[1, 8])
+    ap.add_argument("--size", type=int, default=None, help="override image side (exploratory)")
+    ap.add_argument("--block", type=int, default=None, choices=[4, 8, 16], help="override B (exploratory)")
     ap.add_argument("--dist", default="U", choices=["U", "S", "lena"],
                     help="synthetic input: U = iid bytes (the quoted distribution), S = flat tiles + noise, "
                          "lena = LenaGrey.png tiled/cropped to size with a per-image shift (robustness checks)")
@@ -115,6 +117,10 @@ def main():
     import fic_amd
 
     wl = dict(WORKLOADS[args.workload])
+    if args.size or args.block:                         # exploratory overrides (not a BASELINE.json configuration)
+        wl["W"] = wl["H"] = args.size or wl["W"]
+        wl["B"] = args.block or wl["B"]
+        wl["desc"] = f"{args.workload} with overrides: {wl['W']}x{wl['H']} synthetic grey U, B={wl['B']}, full search"
     if args.planes:
         wl["planes"] = args.planes
     if args.n_iso:
@@ -278,7 +284,7 @@ def main():
             out["valu"] = {"bound": "valu-issue (epilogue)", "valu_instr_per_pair_eval": vpe,
                            "frac": pair_evals * vpe / 64.0 / (avg_ms * 1e-3) / VALU_WAVE_INSTR_PEAK,
                            "peak_wave_instr_per_s": VALU_WAVE_INSTR_PEAK}
-        if info["sweep_kind"] == 2 and ((B == 8 and n_iso == 8) or n_iso == 1) and world == 1 and not args.no_alt:
+        if info["sweep_kind"] == 2 and world == 1 and not args.no_alt:
             # Same workload, same buffers, through the opt-in matrix-core sweep: reported beside, never as `value`.
             core.set_option("sweep", 3)
             for _ in range(args.warmup):

@@ -361,11 +361,10 @@ int fic_ctx_encode(fic_ctx* c, int range_begin, int range_count, void* hip_strea
         // FIC_SWEEP=3 opts the whole process into the matrix-core sweep wherever it is built (same results);
         // other geometries keep the VALU sweep.  An explicit fic_ctx_set_option("sweep", ...) wins.
         const char* env = getenv("FIC_SWEEP");
-        if (env && env[0] == '3' && env[1] == '\0' && g.full && ((g.B == 8 && g.n_iso == 8) || g.n_iso == 1)) kind = 3;
+        if (env && env[0] == '3' && env[1] == '\0' && g.full) kind = 3;
     }
     if (kind >= 2 && !g.full) return fail(FIC_E_ARGUMENT, "fast sweep needs full search (wK == Dw == Dh)");
-    if (kind == 3 && !((g.B == 8 && g.n_iso == 8) || g.n_iso == 1))
-        return fail(FIC_E_ARGUMENT, "the matrix-core sweep is built for n_iso = 1 (B = 4, 8, 16) and for B = 8, n_iso = 8");
+
     const int tsz = 64 * g.NR;
     const int tile0 = range_begin / tsz;
     const int tile1 = (range_begin + range_count + tsz - 1) / tsz;
@@ -388,11 +387,13 @@ int fic_ctx_encode(fic_ctx* c, int range_begin, int range_count, void* hip_strea
         const bool iso8 = g.n_iso == 8;
         const int NM = g.n <= 32 ? 1 : g.n / 32;                      // K = 32 MFMA steps per block
         const int nctiles = g.Nr_pad / 32, nctiles_alloc = nctiles + 32; // column tiles (x32 ranges), n_iso = 1 kernel
+        const int G8 = fic_mfma8_group(g.B);                          // range blocks per workgroup, n_iso = 8 kernel
+        const int ngroups8 = (g.Nr_pad + G8 - 1) / G8;
         if (!c->mfma_poolB) {
             if (iso8) {
-                HIP_TRY(hipMalloc(&c->mfma_poolB, P * ndtiles_alloc * 128 * 16));
-                HIP_TRY(hipMalloc(&c->mfma_rngA, P * g.tiles * FIC_MFMA_RT_HOST * 128 * 16));
-                HIP_TRY(hipMalloc((void**)&c->mfma_rconst, P * g.tiles * FIC_MFMA_RT_HOST * 16 * sizeof(int)));
+                HIP_TRY(hipMalloc(&c->mfma_poolB, P * ndtiles_alloc * NM * 64 * 16));
+                HIP_TRY(hipMalloc(&c->mfma_rngA, P * ngroups8 * (G8 / 4) * NM * 64 * 16));   // 32 KiB per group
+                HIP_TRY(hipMalloc((void**)&c->mfma_rconst, P * ngroups8 * (G8 / 4) * 16 * sizeof(int)));
             } else {
                 HIP_TRY(hipMalloc(&c->mfma_poolB, P * ndtiles_alloc * NM * 64 * 16));
                 HIP_TRY(hipMalloc(&c->mfma_sw, P * ndtiles_alloc * 32 * 8));
@@ -404,7 +405,7 @@ int fic_ctx_encode(fic_ctx* c, int range_begin, int range_count, void* hip_strea
         if (c->opt_time) { hipEventDestroy(e0); hipEventDestroy(e1); e0 = e1 = nullptr; }
         if (iso8) {
             if (fic_launch_mfma_prep_pool(c->b.pool_pix, c->mfma_poolB, g, ndtiles_alloc, s) ||
-                fic_launch_mfma_prep_range(c->b.rng_pix, c->b.rng_st, c->mfma_rngA, c->mfma_rconst, g, s))
+                fic_launch_mfma_prep_range(c->b.rng_pix, c->b.rng_st, c->mfma_rngA, c->mfma_rconst, g, ngroups8, s))
                 return fail(FIC_E_HIP, "mfma prep launch failed");
         } else if (fic_launch_mfma1_prep(c->b, c->mfma_poolB, c->mfma_sw, c->mfma_rngA, c->mfma_rconst, g, ndtiles_alloc,
                                          nctiles_alloc, s)) {
@@ -417,7 +418,7 @@ int fic_ctx_encode(fic_ctx* c, int range_begin, int range_count, void* hip_strea
         }
         nchunks = c->opt_chunks;
         if (nchunks <= 0) {
-            long long base_wg = iso8 ? (long long)ntiles * g.planes   // workgroups per chunk (256 CUs x ~4 resident)
+            long long base_wg = iso8 ? ((long long)ntiles * tsz + G8 - 1) / G8 * g.planes   // workgroups per chunk
                                      : ((long long)ntiles * tsz / 32 + fic_mfma1_ct(g.B) - 1) / fic_mfma1_ct(g.B) * g.planes;
             long long want = (4096 + base_wg - 1) / base_wg;
             long long cap = ndtiles / 256;                            // >= 256 domain tiles per chunk: start-up cost < 10 %
@@ -430,7 +431,8 @@ int fic_ctx_encode(fic_ctx* c, int range_begin, int range_count, void* hip_strea
         nchunks = (ndtiles + tiles_per_chunk - 1) / tiles_per_chunk;
         if (nchunks > 65535) return fail(FIC_E_ARGUMENT, "too many chunks (%d)", nchunks);
         if (iso8) {
-            if (fic_launch_sweep_mfma(c->b, c->mfma_poolB, c->mfma_rngA, c->mfma_rconst, g, tile0, ntiles, ndtiles,
+            const int g0 = (tile0 * tsz) / G8, g1 = (tile1 * tsz + G8 - 1) / G8;   // groups covering the tile span
+            if (fic_launch_sweep_mfma(c->b, c->mfma_poolB, c->mfma_rngA, c->mfma_rconst, g, ngroups8, g0, g1 - g0, ndtiles,
                                       ndtiles_alloc, tiles_per_chunk, nchunks, s))
                 return fail(FIC_E_HIP, "k_sweep_mfma launch failed");
         } else {

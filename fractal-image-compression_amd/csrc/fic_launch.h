@@ -72,15 +72,14 @@ struct FicRgbBuffers {
 int fic_launch_rgb_encode(const FicRgbBuffers& b, const FicRgbOutputs& out, int32_t* collage, const FicGeom& g,
                           hipStream_t s);
 
-// opt-in matrix-core sweep ("sweep" = 3)
-#define FIC_MFMA_RT_HOST 16
+// opt-in matrix-core sweeps ("sweep" = 3)
+int fic_mfma8_group(int B);          // range blocks per workgroup of the 8-isometry kernel
 int fic_launch_mfma_prep_pool(const uint8_t* pool_pix, void* poolB, const FicGeom& g, int ndtiles_alloc, hipStream_t s);
 int fic_launch_mfma_prep_range(const uint32_t* rng_pix, const FicRngStat* rng_st, void* rngA, int* rconst,
-                               const FicGeom& g, hipStream_t s);
+                               const FicGeom& g, int ngroups, hipStream_t s);
 int fic_launch_sweep_mfma(const FicBuffers& b, const void* poolB, const void* rngA, const int* rconst, const FicGeom& g,
-                          int group0, int ngroups_launch, int ndtiles, int ndtiles_alloc, int tiles_per_chunk, int nchunks,
-                          hipStream_t s);
-
+                          int ngroups, int group0, int ngroups_launch, int ndtiles, int ndtiles_alloc, int tiles_per_chunk,
+                          int nchunks, hipStream_t s);
 int fic_mfma1_ct(int B);
 int fic_launch_mfma1_prep(const FicBuffers& b, void* poolA, void* pool_sw, void* rngB, void* rconst, const FicGeom& g,
                           int ndtiles_alloc, int nctiles_alloc, hipStream_t s);

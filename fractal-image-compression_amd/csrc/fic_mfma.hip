@@ -36,49 +36,60 @@
 // ---------------------------------------------------------------------------------------------
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
-#define FIC_MFMA_RT 16                     // row tiles per workgroup: 16 x 4 = 64 range blocks
-#define FIC_TAU_ALL 4096.0f                // >= |cov| / sqrt(var) for any pair (|cov| <= 2040 * sqrt(var))
+#define FIC_TAU_ALL 8192.0f                // > |cov| / sqrt(var) for any pair (|cov| <= sqrt(n)*255*sqrt(var) <= 4080*sqrt(var))
+// NM = MFMA steps of K = 32 per block (B = 4: 1 with the upper half of K zero, B = 8: 2, B = 16: 8).
+// Row tiles (4 range blocks x 8 isometry copies) per workgroup: always 32 KiB of A fragments.
+__host__ __device__ constexpr int mfma8_rt(int NM) { return NM == 1 ? 32 : NM == 2 ? 16 : 4; }
 
-// pool -> B fragments: poolB[plane][dtile][m][lane] = 16 bytes of domain (dtile*32 + lane&31), i8-shifted
+// pool -> B fragments: poolB[plane][dtile][m][lane] = bytes [32m+16h, +16) of domain block dtile*32 + (lane&31),
+// i8-shifted (x ^ 0x80); blocks beyond N_d read as pixel 0 (so their covariance is exactly 0), bytes beyond n as i8 0.
 __global__ __launch_bounds__(256) void k_pool_mfma(const uint8_t* __restrict__ pool_pix, v4i* __restrict__ poolB,
-                                                   FicGeom g, int ndtiles_alloc)
+                                                   FicGeom g, int ndtiles_alloc, int NM)
 {
     int i = blockIdx.x * 256 + threadIdx.x;            // (dtile, m, lane)
     int plane = blockIdx.y;
-    if (i >= ndtiles_alloc * 128) return;
-    int lane = i & 63, m = (i >> 6) & 1, dtile = i >> 7;
+    if (i >= ndtiles_alloc * NM * 64) return;
+    int lane = i & 63, m = (i >> 6) % NM, dtile = (i >> 6) / NM;
     int d = dtile * 32 + (lane & 31), h = lane >> 5;
-    v4i v = {(int)0x80808080, (int)0x80808080, (int)0x80808080, (int)0x80808080};   // pixel 0 for the padding blocks
-    if (d < g.Nd) {
-        v = *(const v4i*)(pool_pix + ((size_t)plane * g.Nd_pad + d) * 64 + 32 * m + 16 * h);
-        v ^= (v4i){(int)0x80808080, (int)0x80808080, (int)0x80808080, (int)0x80808080};
+    int off = 32 * m + 16 * h;
+    v4i v = {0, 0, 0, 0};
+    if (off < g.n) {
+        v = (v4i){(int)0x80808080, (int)0x80808080, (int)0x80808080, (int)0x80808080};
+        if (d < g.Nd) v ^= *(const v4i*)(pool_pix + ((size_t)plane * g.Nd_pad + d) * g.n + off);
     }
-    poolB[(size_t)plane * ndtiles_alloc * 128 + i] = v;
+    poolB[(size_t)plane * ndtiles_alloc * NM * 64 + i] = v;
 }
 
-// ranges -> A fragments + per-range constants {K = 128*Sr - 16384*n, A = 128 - rM, negR = -rem}
+// ranges -> A fragments (row = 8q + k of a row tile: range block 4t+q, isometry copy k) + per-range constants
+// {K = 128*Sr - 16384*n, A = 128 - rM, negR = -rem}, 16 ints per row tile
 __global__ __launch_bounds__(256) void k_range_mfma(const uint32_t* __restrict__ rng_pix,
                                                     const FicRngStat* __restrict__ rng_st, v4i* __restrict__ rngA,
-                                                    int* __restrict__ rconst, FicGeom g)
+                                                    int* __restrict__ rconst, FicGeom g, int NM, int RT, int ngroups)
 {
     int i = blockIdx.x * 256 + threadIdx.x;            // (group, t, m, lane)
     int plane = blockIdx.y;
-    int total = g.tiles * FIC_MFMA_RT * 128;
+    int total = ngroups * RT * NM * 64;
     if (i >= total) return;
-    int lane = i & 63, m = (i >> 6) & 1, t = (i >> 7) % FIC_MFMA_RT, group = (i >> 7) / FIC_MFMA_RT;
+    int lane = i & 63, m = (i >> 6) % NM, t = ((i >> 6) / NM) % RT, group = ((i >> 6) / NM) / RT;
     int r = lane & 31, h = lane >> 5, q = r >> 3, k = r & 7;
-    int j = group * 64 + 4 * t + q;
+    int j = (group * RT + t) * 4 + q;
+    int off = 32 * m + 16 * h;
     const uint32_t* rp = rng_pix + (size_t)plane * g.Nr_pad * g.n_iso * g.DW;
-    v4i v;
+    v4i v = {0, 0, 0, 0};
+    if (off < g.n) {
 #pragma unroll
-    for (int w = 0; w < 4; w++) v[w] = (int)(rp[rng_word_index(g, j, k, 8 * m + 4 * h + w)] ^ 0x80808080u);
+        for (int w = 0; w < 4; w++)
+            v[w] = (int)((j < g.Nr_pad ? rp[rng_word_index(g, j, k, off / 4 + w)] : 0u) ^ 0x80808080u);
+    }
     rngA[(size_t)plane * total + i] = v;
     if (m == 0 && lane < 16) {                          // 16 ints per (group, t)
         int qq = lane & 3, what = lane >> 2;
-        FicRngStat st = rng_st[(size_t)plane * g.Nr_pad + group * 64 + 4 * t + qq];
+        int jj = (group * RT + t) * 4 + qq;
+        FicRngStat st = {0, 0};
+        if (jj < g.Nr_pad) st = rng_st[(size_t)plane * g.Nr_pad + jj];
         int Sr = st.rM * g.n + st.rem;
         int val = what == 0 ? 128 * Sr - 16384 * g.n : what == 1 ? 128 - st.rM : what == 2 ? -st.rem : 0;
-        rconst[((size_t)plane * g.tiles * FIC_MFMA_RT + (size_t)group * FIC_MFMA_RT + t) * 16 + lane] = val;
+        rconst[(((size_t)plane * ngroups + group) * RT + t) * 16 + lane] = val;
     }
 }
 
@@ -89,16 +100,17 @@ struct MfmaArgs {
     const v4i* rngA;
     const int* rconst;
     unsigned long long* key;
-    int Nd, Nd_pad, Nr_pad, lgn;
+    int Nd, Nd_pad, Nr, Nr_pad, lgn;
     int ndtiles, ndtiles_alloc, ngroups;
     int group0, ngroups_launch;      // first range group of this shard, groups in this launch
     int tiles_per_chunk, nchunks, planes;
 };
 
+template <int NM>
 __global__ __launch_bounds__(256) void k_sweep_mfma(MfmaArgs A)
 {
-    constexpr int RT = FIC_MFMA_RT;
-    __shared__ v4i sA[RT * 2 * 64];                    // 32 KiB: A fragments of 64 range blocks x 8 copies
+    constexpr int RT = mfma8_rt(NM);
+    __shared__ v4i sA[RT * NM * 64];                   // 32 KiB: A fragments of RT*4 range blocks x 8 copies
     __shared__ __attribute__((aligned(16))) uint32_t sTau[RT * 4];   // per range: prune threshold (f32 bits, >= 0);
                                                                      // range 4t+q belongs to the wave that owns row tile t
     const int lane = threadIdx.x & 63;
@@ -107,34 +119,39 @@ __global__ __launch_bounds__(256) void k_sweep_mfma(MfmaArgs A)
     xcd_decode(blockIdx.x, A.nchunks * A.planes, A.ngroups_launch, combo_, gx_);
     const int group = A.group0 + gx_;
     const int plane = combo_ / A.nchunks;
-    const int chunk = combo_ % A.nchunks;                      // all 4 waves sweep the same pool chunk (B tiles hit in L1) ...
-    const int t_first = wave * (RT / 4);               // ... and split the 16 row tiles
+    const int chunk = combo_ % A.nchunks;              // all 4 waves sweep the same pool chunk (B tiles hit in L1) ...
+    const int t_first = wave * (RT / 4);               // ... and split the row tiles
     const size_t gbase = (size_t)plane * A.ngroups + group;
     const AS4 int* rc_base = (const AS4 int*)A.rconst + gbase * RT * 16;
 
-    for (int i = threadIdx.x; i < RT * 2 * 64; i += 256) sA[i] = A.rngA[gbase * RT * 128 + i];
+    for (int i = threadIdx.x; i < RT * NM * 64; i += 256) sA[i] = A.rngA[gbase * RT * NM * 64 + i];
     // ranges with rem == 0: error 0 for every block (FC:677) -> nothing after the first tile can win
-    if (wave == 0) sTau[lane] = (A.rconst[(gbase * RT + (lane >> 2)) * 16 + 8 + (lane & 3)] == 0) ? __float_as_uint(FIC_TAU_ALL) : 0u;
+    if (threadIdx.x < RT * 4)
+        sTau[threadIdx.x] = (A.rconst[(gbase * RT + (threadIdx.x >> 2)) * 16 + 8 + (threadIdx.x & 3)] == 0)
+                                ? __float_as_uint(FIC_TAU_ALL) : 0u;
     __syncthreads();
-    if (chunk >= A.nchunks) return;
     const int dt0 = chunk * A.tiles_per_chunk;
     int dt1 = dt0 + A.tiles_per_chunk;
     if (dt1 > A.ndtiles) dt1 = A.ndtiles;
     if (dt0 >= dt1) return;
 
     const int jcol = lane & 31, half = lane >> 5;
-    const v4i* pb = A.poolB + (size_t)plane * A.ndtiles_alloc * 128;
+    const v4i* pb = A.poolB + (size_t)plane * A.ndtiles_alloc * NM * 64;
     const FicDomStat* pst = A.pool_st + (size_t)plane * A.Nd_pad;
     const double* p64 = A.pool_s64 + (size_t)plane * A.Nd_pad;
-    unsigned long long* keyp = A.key + (size_t)plane * A.Nr_pad + (size_t)group * 64;
+    const int jbase = group * RT * 4;                   // first range block of the workgroup
+    unsigned long long* keyp = A.key + (size_t)plane * A.Nr_pad;
     const v16i zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 
-    v4i b0 = pb[(size_t)dt0 * 128 + lane], b1 = pb[(size_t)dt0 * 128 + 64 + lane];
+    v4i b[NM], nb[NM];
+#pragma unroll
+    for (int m = 0; m < NM; m++) b[m] = pb[((size_t)dt0 * NM + m) * 64 + lane];
     int dcur = dt0 * 32 + jcol;
     FicDomStat st = pst[dcur < A.Nd_pad ? dcur : 0];
     for (int dt = dt0; dt < dt1; dt++) {
         // prefetch the next domain tile (the fragment store has one spare tile)
-        v4i nb0 = pb[(size_t)(dt + 1) * 128 + lane], nb1 = pb[(size_t)(dt + 1) * 128 + 64 + lane];
+#pragma unroll
+        for (int m = 0; m < NM; m++) nb[m] = pb[((size_t)(dt + 1) * NM + m) * 64 + lane];
         int dnext = (dt + 1) * 32 + jcol;
         FicDomStat nst = pst[dnext < A.Nd_pad ? dnext : 0];
         const int d = dt * 32 + jcol;
@@ -145,11 +162,12 @@ __global__ __launch_bounds__(256) void k_sweep_mfma(MfmaArgs A)
         const bool force = (dt == dt0);                 // wave-uniform
 
         for (int t = t_first; t < t_first + RT / 4; t++) {
-            v4i a0 = sA[(t * 2 + 0) * 64 + lane], a1 = sA[(t * 2 + 1) * 64 + lane];
             const uint4 tau4 = *(const uint4*)&sTau[t * 4];
             const AS4 int* rc = rc_base + t * 16;       // wave-uniform -> scalar loads
-            v16i acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, b0, zero, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, b1, acc, 0, 0, 0);
+            v16i acc = zero;
+#pragma unroll
+            for (int m = 0; m < NM; m++)
+                acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(sA[(t * NM + m) * 64 + lane], b[m], acc, 0, 0, 0);
 
             // Per range q: cov_e = acc[e] + Kq + Aq*sum(d) - rem*dM (exact, 24-bit operands); the pair needs the
             // exact epilogue iff |cov_e| > li = floor(tau*s32)  <=>  (unsigned)(cov_e + li) > 2*li.
@@ -163,7 +181,7 @@ __global__ __launch_bounds__(256) void k_sweep_mfma(MfmaArgs A)
                 int lin;
                 asm("v_mul_i32_i24 %0, %1, %2" : "=v"(lin) : "s"(nRq), "v"(dM));
                 asm("v_mad_i32_i24 %0, %1, %2, %0" : "+v"(lin) : "s"(Aq), "v"(Sd));
-                const int li = (int)__fmul_rn(tau, s32);            // < 2^30 by construction (tau <= 4096, s32 <= 4080)
+                const int li = (int)__fmul_rn(tau, s32);            // < 2^30 by construction (tau <= 8192, s32 <= 4080)
                 offq[q] = (uint32_t)(lin + Kq + li);
                 spanq[q] = 2u * (uint32_t)li;
                 const uint32_t u0 = (uint32_t)acc[4 * q + 0] + offq[q], u1 = (uint32_t)acc[4 * q + 1] + offq[q];
@@ -177,14 +195,15 @@ __global__ __launch_bounds__(256) void k_sweep_mfma(MfmaArgs A)
 #pragma unroll
                 for (int e = 0; e < 16; e++) {
                     const int q = e >> 2;
-                    if (!((anyq[q] || force) && valid)) continue;       // whole range untouched on this lane: skip its 4 copies
+                    const int j = jbase + 4 * t + q;
+                    if (!((anyq[q] || force) && valid && j < A.Nr)) continue;   // whole range untouched on this lane
                     const uint32_t u = (uint32_t)acc[e] + offq[q];
                     if (u > spanq[q] || force) {
                         const int cov = (int)(u - (spanq[q] >> 1));
                         const int rem = -rc[8 + q];
                         const float err = exact_error(cov, rem, s64);
                         const uint32_t cand = (uint32_t)d * 8u + (uint32_t)((e & 3) + 4 * half);
-                        atomicMin(&keyp[4 * t + q], ((unsigned long long)f32_orderable(err) << 32) | cand);
+                        atomicMin(&keyp[j], ((unsigned long long)f32_orderable(err) << 32) | cand);
                         if (rem != 0) {
                             float lvl = (s32 == 0.0f) ? 0.0f
                                                       : __fmul_rn(__fdiv_rn(fabsf((float)cov), s32), 0.99999618530273437500f);
@@ -194,7 +213,9 @@ __global__ __launch_bounds__(256) void k_sweep_mfma(MfmaArgs A)
                 }
             }
         }
-        b0 = nb0; b1 = nb1; st = nst;
+#pragma unroll
+        for (int m = 0; m < NM; m++) b[m] = nb[m];
+        st = nst;
     }
 }
 
@@ -378,37 +399,42 @@ __global__ __launch_bounds__(256) void k_range_mfma1(const uint32_t* __restrict_
 }
 
 // host-side launchers
-// opt-in matrix-core sweep (B = 8, n_iso = 8): fragment prep + sweep
+// opt-in matrix-core sweep, n_iso = 8 (B = 4 / 8 / 16): fragment prep + sweep
+static int mfma_nm(const FicGeom& g) { return g.n <= 32 ? 1 : g.n / 32; }
+int fic_mfma8_group(int B) { return mfma8_rt(B == 4 ? 1 : B == 8 ? 2 : 8) * 4; }     // range blocks per workgroup
 int fic_launch_mfma_prep_pool(const uint8_t* pool_pix, void* poolB, const FicGeom& g, int ndtiles_alloc, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_pool_mfma, dim3((ndtiles_alloc * 128 + 255) / 256, g.planes), dim3(256), 0, s, pool_pix,
-                       (v4i*)poolB, g, ndtiles_alloc);
+    const int NM = mfma_nm(g);
+    hipLaunchKernelGGL(k_pool_mfma, dim3((ndtiles_alloc * NM * 64 + 255) / 256, g.planes), dim3(256), 0, s, pool_pix,
+                       (v4i*)poolB, g, ndtiles_alloc, NM);
     FIC_LAUNCH_CHECK();
     return 0;
 }
-
 int fic_launch_mfma_prep_range(const uint32_t* rng_pix, const FicRngStat* rng_st, void* rngA, int* rconst,
-                               const FicGeom& g, hipStream_t s)
+                               const FicGeom& g, int ngroups, hipStream_t s)
 {
-    int total = g.tiles * FIC_MFMA_RT * 128;
+    const int NM = mfma_nm(g), RT = mfma8_rt(NM);
+    int total = ngroups * RT * NM * 64;
     hipLaunchKernelGGL(k_range_mfma, dim3((total + 255) / 256, g.planes), dim3(256), 0, s, rng_pix, rng_st, (v4i*)rngA,
-                       rconst, g);
+                       rconst, g, NM, RT, ngroups);
     FIC_LAUNCH_CHECK();
     return 0;
 }
-
 int fic_launch_sweep_mfma(const FicBuffers& b, const void* poolB, const void* rngA, const int* rconst, const FicGeom& g,
-                          int group0, int ngroups_launch, int ndtiles, int ndtiles_alloc, int tiles_per_chunk, int nchunks,
-                          hipStream_t s)
+                          int ngroups, int group0, int ngroups_launch, int ndtiles, int ndtiles_alloc, int tiles_per_chunk,
+                          int nchunks, hipStream_t s)
 {
     MfmaArgs A;
     A.poolB = (const v4i*)poolB; A.pool_st = b.pool_st; A.pool_s64 = b.pool_s64;
     A.rngA = (const v4i*)rngA; A.rconst = rconst; A.key = b.key;
-    A.Nd = g.Nd; A.Nd_pad = g.Nd_pad; A.Nr_pad = g.Nr_pad; A.lgn = g.lgn;
-    A.ndtiles = ndtiles; A.ndtiles_alloc = ndtiles_alloc; A.ngroups = g.tiles;
+    A.Nd = g.Nd; A.Nd_pad = g.Nd_pad; A.Nr = g.Nr; A.Nr_pad = g.Nr_pad; A.lgn = g.lgn;
+    A.ndtiles = ndtiles; A.ndtiles_alloc = ndtiles_alloc; A.ngroups = ngroups;
     A.group0 = group0; A.ngroups_launch = ngroups_launch; A.tiles_per_chunk = tiles_per_chunk; A.nchunks = nchunks;
     A.planes = g.planes;
-    hipLaunchKernelGGL(k_sweep_mfma, dim3((unsigned)(nchunks * g.planes) * (unsigned)ngroups_launch), dim3(256), 0, s, A);
+    dim3 grid((unsigned)(nchunks * g.planes) * (unsigned)ngroups_launch), block(256);
+    if (g.B == 4) hipLaunchKernelGGL((k_sweep_mfma<1>), grid, block, 0, s, A);
+    else if (g.B == 8) hipLaunchKernelGGL((k_sweep_mfma<2>), grid, block, 0, s, A);
+    else hipLaunchKernelGGL((k_sweep_mfma<8>), grid, block, 0, s, A);
     FIC_LAUNCH_CHECK();
     return 0;
 }

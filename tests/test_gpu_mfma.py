@@ -78,10 +78,6 @@ def test_mfma_shards_and_1024():
 
 def test_mfma_is_refused_outside_its_configuration():
     with pytest.raises(fic_amd.FicError):
-        fic_amd.encode_gray(IMAGES["lena256"], 16, None, 8, sweep=3)
-    with pytest.raises(fic_amd.FicError):
-        fic_amd.encode_gray(IMAGES["lena256"], 4, None, 8, sweep=3)
-    with pytest.raises(fic_amd.FicError):
         fic_amd.encode_gray(IMAGES["lena256"], 8, 16, 1, sweep=3)       # windowed search is not a sweep
 
 
@@ -145,5 +141,43 @@ def test_fic_sweep_environment_opt_in(tmp_path):
         subprocess.check_call([sys.executable, "-c", code, k, q], env={**os.environ, **env})
         res[tag] = (np.load(k), np.load(q))
     assert res["valu"][0].tolist() == [2, 2, 2]
-    assert res["mfma"][0].tolist() == [3, 3, 2]          # (8,1), (8,8) switch; (16,8) keeps the VALU sweep
+    assert res["mfma"][0].tolist() == [3, 3, 3]          # every full-search configuration has a matrix-core sweep
     assert (res["valu"][1] == res["mfma"][1]).all()
+
+
+# ---- n_iso = 8 at B = 4 and B = 16 (k_sweep_mfma<1>, <8>) ------------------------------------------------------
+
+ISO8_OTHER = [(n, B) for n in sorted(IMAGES) for B in (4, 16)
+              if not (n in ("lena64", "flat64", "U200", "S200") and B == 16) and not (n in ("lena256", "S256", "U256") and B == 4)]
+
+
+@pytest.mark.parametrize("name,B", ISO8_OTHER)
+def test_mfma_8iso_other_block_sizes_match_oracle(oracle, name, B):
+    g = IMAGES[name]
+    h, w = g.shape
+    Dw = fic_amd.geometry(w, h, B)[2]
+    ref = oracle.encode_gray(oracle.gray_to_argb(g), w, h, B, Dw, 8)
+    for chunks in (0, 2):
+        got = fic_amd.encode_gray(g, B, None, 8, sweep=3, chunks=chunks)
+        assert (got["idx_local"] == ref["info"][:, 0].astype(np.int32)).all()
+        assert (got["iso"] == ref["iso"]).all()
+        assert same_f32(got["a"], ref["info"][:, 1]) and same_f32(got["b"], ref["info"][:, 2])
+        assert (got["qrows"] == oracle.quantise_gray(ref["info"])).all()
+        assert same_f32(got["err"], ref["err"])
+
+
+@pytest.mark.parametrize("B,size", [(4, 512), (16, 1024)])
+def test_mfma_8iso_other_block_sizes_equal_valu_sweep_at_scale_and_sharded(B, size):
+    imgs = np.stack([synth.image_u(size, size, 41 + B), synth.image_s(size, size, 42 + B)])
+    with fic_amd.Encoder(size, size, B, None, 8, planes=2) as enc:
+        enc.set_gray(imgs)
+        enc.set_option("sweep", 2)
+        enc.encode()
+        valu = enc.results()
+        enc.set_option("sweep", 3)
+        parts = []
+        for b, c in fic_amd.shard_spans(enc.n_ranges, enc.ranges_per_tile, 3):   # odd tile offsets: misaligned groups at B = 4
+            enc.encode(b, c)
+            r = enc.results()
+            parts.append({k: v[:, b:b + c].copy() for k, v in r.items()})
+    _same({k: np.concatenate([p[k] for p in parts], axis=1) for k in parts[0]}, valu)
