@@ -1,4 +1,4 @@
-// fic_mfma.hip -- OPT-IN matrix-core sweeps ("sweep" = 3): k_sweep_mfma (B = 8, 8 iso), k_sweep_mfma1 (1 iso, B = 4/8/16).
+// fic_mfma.hip -- OPT-IN matrix-core sweeps ("sweep" = 3): k_sweep_mfma<NM> (8 iso) and k_sweep_mfma1<NM> (1 iso), B = 4/8/16.
 // gfx950 (MI355X / CDNA4) only, wave64.  Compile with -ffp-contract=off: every float expression must round once
 // per operation exactly like the Java reference (FractalCompression.java = FC, Domainblock.java = DB).
 #include <hip/hip_runtime.h>
