@@ -9,7 +9,7 @@
 #include "fic_devfn.h"
 
 // ---------------------------------------------------------------------------------------------
-// k_sweep_mfma : OPT-IN matrix-core variant of the full-pool sweep ("sweep" = 3; B = 8, n_iso = 8).
+// k_sweep_mfma<NM> : OPT-IN matrix-core variant of the full-pool sweep ("sweep" = 3; n_iso = 8; B = 4/8/16).
 //
 // north_star asks for a VALU-only sweep and k_sweep_fast is that kernel (and the default).  It
 // is pinned at the v_dot4 issue ceiling; the inner products of all (range copy,
@@ -26,13 +26,15 @@
 //               are wave-uniform -- and isometry k = (e&3) + 4*(lane>>5).
 //   cols (B)  = 32 consecutive domain blocks, streamed; lane&31 = the lane's domain, whose
 //               {sum, sqrt(var)} sit in two VGPRs.
-//   K = 64 pixels = 2 MFMAs; lane (r, h) supplies bytes [32m+16h, 32m+16h+16) of its row/col for
-//   MFMA m -- the same map on both operands, so any k order is consistent.
-//   A workgroup (4 waves) shares 64 range blocks (16 row tiles) through LDS and each wave
-//   sweeps its own pool chunk; tau (the prune threshold) is private to a wave, kept in LDS and
-//   raised with ds_max_u32 by the rare exact path; winners go straight to the global key with
-//   the same 64-bit atomicMin as k_sweep_fast.  The first domain tile of a chunk is always
-//   evaluated exactly (it initialises tau).
+//   K = n pixels = NM MFMA steps of 32 (B = 4: one step, upper half zero); lane (r, h) supplies bytes
+//   [32m+16h, 32m+16h+16) of its row/col for step m -- the same map on both operands, so any k
+//   order is consistent.
+//   A workgroup (4 waves) keeps 32 KiB of A fragments in LDS (32/16/4 row tiles for B = 4/8/16); its
+//   waves split the row tiles and all sweep the same pool chunk (their B-tile loads hit in L1).
+//   tau (the prune threshold) of a range belongs to the wave that owns its row tile; it lives in
+//   LDS and is raised with ds_max_u32 by the rare exact path; winners go straight to the global
+//   key with the same 64-bit atomicMin as k_sweep_fast.  The first domain tile of a chunk is
+//   always evaluated exactly (it initialises tau).
 // ---------------------------------------------------------------------------------------------
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
