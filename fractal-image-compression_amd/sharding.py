@@ -9,6 +9,7 @@ one gather of 24 bytes per range block (the IFS codebook rows) -- latency-bound 
 import numpy as np
 
 RECORD_WORDS = 6   # idx_local, a bits, b bits, iso, (int)(a*100), (int)b
+_USE_ALL_GATHER = False   # set when the backend turns out to have no gather (see gather_records)
 
 
 def shard_spans(n_ranges, ranges_per_tile, world):
@@ -70,12 +71,25 @@ def gather_records(local, spans, group=None, dst=0):
     planes = local.shape[0]
     pad = torch.zeros((planes, maxc, RECORD_WORDS), dtype=torch.int32, device=local.device)
     pad[:, : local.shape[1]] = local
-    if rank == dst:
-        bufs = [torch.empty_like(pad) for _ in range(world)]
-        dist.gather(pad, bufs, dst=dst, group=group)
-        return torch.cat([bufs[r][:, : spans[r][1]] for r in range(world)], dim=1)
-    dist.gather(pad, None, dst=dst, group=group)
-    return None
+    global _USE_ALL_GATHER
+    if not _USE_ALL_GATHER:
+        try:
+            if rank == dst:
+                bufs = [torch.empty_like(pad) for _ in range(world)]
+                dist.gather(pad, bufs, dst=dst, group=group)
+                return torch.cat([bufs[r][:, : spans[r][1]] for r in range(world)], dim=1)
+            dist.gather(pad, None, dst=dst, group=group)
+            return None
+        except (NotImplementedError, RuntimeError) as e:
+            # a backend without gather rejects the call on every rank before communicating: switch once
+            if "gather" not in str(e).lower() and "support" not in str(e).lower():
+                raise
+            _USE_ALL_GATHER = True
+    bufs = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(bufs, pad, group=group)
+    if rank != dst:
+        return None
+    return torch.cat([bufs[r][:, : spans[r][1]] for r in range(world)], dim=1)
 
 
 class ShardedEncoder:
