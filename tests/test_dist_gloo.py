@@ -22,13 +22,15 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, outfile):
+def _worker(rank, world, port, outfile, force_all_gather):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import fic_amd
+    from fic_amd import sharding
     from oracle import fic_oracle as fo
+    sharding._USE_ALL_GATHER = bool(force_all_gather)     # exercise the backend-without-gather fallback too
     g = np.load(os.path.join(ROOT, "tests", "golden", "lena64.npy"))
     B, wK, tile = 4, 29, 64
     argb = fo.gray_to_argb(g)
@@ -48,10 +50,10 @@ def _worker(rank, world, port, outfile):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_sharded_gather_equals_unsharded(tmp_path, world, oracle, lena64):
+@pytest.mark.parametrize("world,force_all_gather", [(2, False), (3, False), (2, True)])
+def test_sharded_gather_equals_unsharded(tmp_path, world, force_all_gather, oracle, lena64):
     out = str(tmp_path / "full.npy")
-    mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), out, force_all_gather), nprocs=world, join=True)
     import fic_amd
     got = fic_amd.unpack_records(np.load(out))
     e = oracle.encode_gray(oracle.gray_to_argb(lena64), 64, 64, 4, 29, n_iso=8)
