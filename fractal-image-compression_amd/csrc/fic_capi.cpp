@@ -185,6 +185,142 @@ void cache_give(fic_ctx* c)
     if (evict) fic_ctx_destroy(evict);
 }
 
+
+// ---- sweep orchestration helpers (used by fic_ctx_encode) ------------------------------------------------------
+
+// "time_sweep": bracket the sweep launch with events on its stream; durations are read later by flush_events.
+int time_begin(fic_ctx* c, hipStream_t s)
+{
+    if (!c->opt_time) return FIC_OK;
+    hipEvent_t e0 = nullptr;
+    HIP_TRY(hipEventCreate(&e0));
+    c->ev.push_back(e0);
+    HIP_TRY(hipEventRecord(e0, s));
+    return FIC_OK;
+}
+int time_end(fic_ctx* c, hipStream_t s)
+{
+    if (!c->opt_time) return FIC_OK;
+    hipEvent_t e1 = nullptr;
+    HIP_TRY(hipEventCreate(&e1));
+    c->ev.push_back(e1);
+    HIP_TRY(hipEventRecord(e1, s));
+    return FIC_OK;
+}
+
+// Default VALU sweep (k_sweep_fast) over tiles [tile0, tile0 + ntiles).
+int valu_sweep(fic_ctx* c, int tile0, int ntiles, hipStream_t s, int* nchunks_out)
+{
+    const FicGeom& g = c->g;
+    int NR, NC;
+    fic_fast_variant(g.B, g.n_iso, &NR, &NC);
+    const long long base_waves = (long long)ntiles * (g.n_iso / NC) * g.planes;
+    int nchunks = c->opt_chunks;
+    if (nchunks <= 0) {
+        // Measured (profiles/r01l_chunk_sweep.txt): every chunk pays a start-up (its first block is evaluated
+        // exactly and tau restarts), so chunks stay >= 4096 blocks while aiming at ~48 K wave tasks for load
+        // balance; only a launch that could not otherwise fill the chip (one small image) splits finer.
+        long long want = (49152 + base_waves - 1) / base_waves;
+        long long cap = g.Nd / 4096;
+        if (cap < 1) cap = 1;
+        long long nc = want < cap ? want : cap;
+        if (base_waves * nc < 4096) {
+            long long cap2 = g.Nd / 512;
+            if (cap2 < 1) cap2 = 1;
+            long long fill = (4096 + base_waves - 1) / base_waves;
+            nc = fill < cap2 ? fill : cap2;
+        }
+        nchunks = (int)(nc < 1 ? 1 : nc);
+    }
+    if (nchunks > g.Nd) nchunks = g.Nd;
+    int chunk_len = (g.Nd + nchunks - 1) / nchunks;
+    chunk_len = (chunk_len + 1) & ~1;              // even: the sweep consumes blocks in pairs
+    nchunks = (g.Nd + chunk_len - 1) / chunk_len;
+    if (fic_launch_sweep_fast(c->b, g, tile0, ntiles, chunk_len, nchunks, s)) return fail(FIC_E_HIP, "k_sweep_fast launch failed");
+    *nchunks_out = nchunks;
+    return FIC_OK;
+}
+
+// Opt-in matrix-core sweeps: geometry of the fragment stores.
+struct MatrixCoreShape {
+    bool iso8;
+    int NM;                          // K = 32 MFMA steps per block
+    int ndtiles, ndtiles_alloc;      // domain tiles (x32 blocks), + 1 spare for the prefetch
+    int nctiles_alloc;               // n_iso = 1: column tiles (x32 ranges), padded for the last workgroup
+    int G8, ngroups8;                // n_iso = 8: range blocks per workgroup, number of groups
+};
+MatrixCoreShape matrix_core_shape(const FicGeom& g)
+{
+    MatrixCoreShape m;
+    m.iso8 = g.n_iso == 8;
+    m.NM = g.n <= 32 ? 1 : g.n / 32;
+    m.ndtiles = (g.Nd + 31) / 32;
+    m.ndtiles_alloc = m.ndtiles + 1;
+    m.nctiles_alloc = g.Nr_pad / 32 + 32;
+    m.G8 = fic_mfma8_group(g.B);
+    m.ngroups8 = (g.Nr_pad + m.G8 - 1) / m.G8;
+    return m;
+}
+int matrix_core_prep(fic_ctx* c, hipStream_t s)
+{
+    const FicGeom& g = c->g;
+    const MatrixCoreShape m = matrix_core_shape(g);
+    const size_t P = (size_t)g.planes;
+    if (!c->mfma_poolB) {
+        HIP_TRY(hipMalloc(&c->mfma_poolB, P * m.ndtiles_alloc * m.NM * 64 * 16));
+        if (m.iso8) {
+            HIP_TRY(hipMalloc(&c->mfma_rngA, P * m.ngroups8 * (m.G8 / 4) * m.NM * 64 * 16));   // 32 KiB per group
+            HIP_TRY(hipMalloc((void**)&c->mfma_rconst, P * m.ngroups8 * (m.G8 / 4) * 16 * sizeof(int)));
+        } else {
+            HIP_TRY(hipMalloc(&c->mfma_sw, P * m.ndtiles_alloc * 32 * 8));
+            HIP_TRY(hipMalloc(&c->mfma_rngA, P * m.nctiles_alloc * m.NM * 64 * 16));
+            HIP_TRY(hipMalloc((void**)&c->mfma_rconst, P * m.nctiles_alloc * 32 * 16));
+        }
+    }
+    if (m.iso8) {
+        if (fic_launch_mfma_prep_pool(c->b.pool_pix, c->mfma_poolB, g, m.ndtiles_alloc, s) ||
+            fic_launch_mfma_prep_range(c->b.rng_pix, c->b.rng_st, c->mfma_rngA, c->mfma_rconst, g, m.ngroups8, s))
+            return fail(FIC_E_HIP, "mfma prep launch failed");
+    } else if (fic_launch_mfma1_prep(c->b, c->mfma_poolB, c->mfma_sw, c->mfma_rngA, c->mfma_rconst, g, m.ndtiles_alloc,
+                                     m.nctiles_alloc, s)) {
+        return fail(FIC_E_HIP, "mfma1 prep launch failed");
+    }
+    return FIC_OK;
+}
+int matrix_core_sweep(fic_ctx* c, int tile0, int tile1, hipStream_t s, int* nchunks_out)
+{
+    const FicGeom& g = c->g;
+    const MatrixCoreShape m = matrix_core_shape(g);
+    const int tsz = 64 * g.NR;
+    int nchunks = c->opt_chunks;
+    if (nchunks <= 0) {
+        const long long ranges = (long long)(tile1 - tile0) * tsz;
+        const long long per_wg = m.iso8 ? m.G8 : 32LL * fic_mfma1_ct(g.B);
+        const long long base_wg = (ranges + per_wg - 1) / per_wg * g.planes;   // workgroups per chunk
+        long long want = (4096 + base_wg - 1) / base_wg;                       // ~4 resident per CU x 256 CUs x 4
+        long long cap = m.ndtiles / 256;                                       // >= 256 domain tiles per chunk: start-up < 10 %
+        if (cap < 1) cap = 1;
+        nchunks = (int)(want < cap ? want : cap);
+        if (nchunks < 1) nchunks = 1;
+    }
+    if (nchunks > m.ndtiles) nchunks = m.ndtiles;
+    const int tiles_per_chunk = (m.ndtiles + nchunks - 1) / nchunks;
+    nchunks = (m.ndtiles + tiles_per_chunk - 1) / tiles_per_chunk;
+    if (m.iso8) {
+        const int g0 = (tile0 * tsz) / m.G8, g1 = (tile1 * tsz + m.G8 - 1) / m.G8;   // groups covering the tile span
+        if (fic_launch_sweep_mfma(c->b, c->mfma_poolB, c->mfma_rngA, c->mfma_rconst, g, m.ngroups8, g0, g1 - g0, m.ndtiles,
+                                  m.ndtiles_alloc, tiles_per_chunk, nchunks, s))
+            return fail(FIC_E_HIP, "k_sweep_mfma launch failed");
+    } else {
+        const int ct_begin = tile0 * (tsz / 32), ct_end = tile1 * (tsz / 32);
+        if (fic_launch_sweep_mfma1(c->b, c->mfma_poolB, c->mfma_sw, c->mfma_rngA, c->mfma_rconst, g, ct_begin, ct_end,
+                                   m.ndtiles, m.ndtiles_alloc, m.nctiles_alloc, tiles_per_chunk, nchunks, s))
+            return fail(FIC_E_HIP, "k_sweep_mfma1 launch failed");
+    }
+    *nchunks_out = nchunks;
+    return FIC_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -372,108 +508,21 @@ int fic_ctx_encode(fic_ctx* c, int range_begin, int range_count, void* hip_strea
     // one 2-D fill: rows = planes (pitch Nr_pad keys), width = the tile span of this shard
     HIP_TRY(hipMemset2DAsync(c->b.key + (size_t)tile0 * tsz, (size_t)g.Nr_pad * sizeof(unsigned long long), 0xFF,
                              (size_t)ntiles * tsz * sizeof(unsigned long long), (size_t)g.planes, s));
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (c->opt_time) {
-        HIP_TRY(hipEventCreate(&e0));
-        HIP_TRY(hipEventCreate(&e1));
-        HIP_TRY(hipEventRecord(e0, s));
-    }
     int nchunks = 1;
-    if (kind == 1) {
-        if (fic_launch_sweep_generic(c->b, g, range_begin, range_count, s)) return fail(FIC_E_HIP, "k_sweep_generic launch failed");
-    } else if (kind == 3) {
-        const int ndtiles = (g.Nd + 31) / 32, ndtiles_alloc = ndtiles + 1;
-        const size_t P = (size_t)g.planes;
-        const bool iso8 = g.n_iso == 8;
-        const int NM = g.n <= 32 ? 1 : g.n / 32;                      // K = 32 MFMA steps per block
-        const int nctiles = g.Nr_pad / 32, nctiles_alloc = nctiles + 32; // column tiles (x32 ranges), n_iso = 1 kernel
-        const int G8 = fic_mfma8_group(g.B);                          // range blocks per workgroup, n_iso = 8 kernel
-        const int ngroups8 = (g.Nr_pad + G8 - 1) / G8;
-        if (!c->mfma_poolB) {
-            if (iso8) {
-                HIP_TRY(hipMalloc(&c->mfma_poolB, P * ndtiles_alloc * NM * 64 * 16));
-                HIP_TRY(hipMalloc(&c->mfma_rngA, P * ngroups8 * (G8 / 4) * NM * 64 * 16));   // 32 KiB per group
-                HIP_TRY(hipMalloc((void**)&c->mfma_rconst, P * ngroups8 * (G8 / 4) * 16 * sizeof(int)));
-            } else {
-                HIP_TRY(hipMalloc(&c->mfma_poolB, P * ndtiles_alloc * NM * 64 * 16));
-                HIP_TRY(hipMalloc(&c->mfma_sw, P * ndtiles_alloc * 32 * 8));
-                HIP_TRY(hipMalloc(&c->mfma_rngA, P * nctiles_alloc * NM * 64 * 16));
-                HIP_TRY(hipMalloc((void**)&c->mfma_rconst, P * nctiles_alloc * 32 * 16));
-            }
-        }
-        // the fragment prep belongs to the pool build / range prep, not to the timed sweep
-        if (c->opt_time) { hipEventDestroy(e0); hipEventDestroy(e1); e0 = e1 = nullptr; }
-        if (iso8) {
-            if (fic_launch_mfma_prep_pool(c->b.pool_pix, c->mfma_poolB, g, ndtiles_alloc, s) ||
-                fic_launch_mfma_prep_range(c->b.rng_pix, c->b.rng_st, c->mfma_rngA, c->mfma_rconst, g, ngroups8, s))
-                return fail(FIC_E_HIP, "mfma prep launch failed");
-        } else if (fic_launch_mfma1_prep(c->b, c->mfma_poolB, c->mfma_sw, c->mfma_rngA, c->mfma_rconst, g, ndtiles_alloc,
-                                         nctiles_alloc, s)) {
-            return fail(FIC_E_HIP, "mfma1 prep launch failed");
-        }
-        if (c->opt_time) {
-            HIP_TRY(hipEventCreate(&e0));
-            HIP_TRY(hipEventCreate(&e1));
-            HIP_TRY(hipEventRecord(e0, s));
-        }
-        nchunks = c->opt_chunks;
-        if (nchunks <= 0) {
-            long long base_wg = iso8 ? ((long long)ntiles * tsz + G8 - 1) / G8 * g.planes   // workgroups per chunk
-                                     : ((long long)ntiles * tsz / 32 + fic_mfma1_ct(g.B) - 1) / fic_mfma1_ct(g.B) * g.planes;
-            long long want = (4096 + base_wg - 1) / base_wg;
-            long long cap = ndtiles / 256;                            // >= 256 domain tiles per chunk: start-up cost < 10 %
-            if (cap < 1) cap = 1;
-            nchunks = (int)(want < cap ? want : cap);
-            if (nchunks < 1) nchunks = 1;
-        }
-        if (nchunks > ndtiles) nchunks = ndtiles;
-        int tiles_per_chunk = (ndtiles + nchunks - 1) / nchunks;
-        nchunks = (ndtiles + tiles_per_chunk - 1) / tiles_per_chunk;
-        if (nchunks > 65535) return fail(FIC_E_ARGUMENT, "too many chunks (%d)", nchunks);
-        if (iso8) {
-            const int g0 = (tile0 * tsz) / G8, g1 = (tile1 * tsz + G8 - 1) / G8;   // groups covering the tile span
-            if (fic_launch_sweep_mfma(c->b, c->mfma_poolB, c->mfma_rngA, c->mfma_rconst, g, ngroups8, g0, g1 - g0, ndtiles,
-                                      ndtiles_alloc, tiles_per_chunk, nchunks, s))
-                return fail(FIC_E_HIP, "k_sweep_mfma launch failed");
+    int rc = FIC_OK;
+    if (kind == 3) rc = matrix_core_prep(c, s);              // fragment prep belongs to pool build / range prep: not timed
+    if (rc == FIC_OK) rc = time_begin(c, s);
+    if (rc == FIC_OK) {
+        if (kind == 1) {
+            if (fic_launch_sweep_generic(c->b, g, range_begin, range_count, s)) rc = fail(FIC_E_HIP, "k_sweep_generic launch failed");
+        } else if (kind == 3) {
+            rc = matrix_core_sweep(c, tile0, tile1, s, &nchunks);
         } else {
-            const int ct_begin = tile0 * (tsz / 32), ct_end = tile1 * (tsz / 32);
-            if (fic_launch_sweep_mfma1(c->b, c->mfma_poolB, c->mfma_sw, c->mfma_rngA, c->mfma_rconst, g, ct_begin, ct_end,
-                                       ndtiles, ndtiles_alloc, nctiles_alloc, tiles_per_chunk, nchunks, s))
-                return fail(FIC_E_HIP, "k_sweep_mfma1 launch failed");
+            rc = valu_sweep(c, tile0, tile1 - tile0, s, &nchunks);
         }
-    } else {
-        int NR, NC;
-        fic_fast_variant(g.B, g.n_iso, &NR, &NC);
-        long long base_waves = (long long)ntiles * (g.n_iso / NC) * g.planes;
-        nchunks = c->opt_chunks;
-        if (nchunks <= 0) {
-            // Measured (profiles/r01l_chunk_sweep.txt): every chunk pays a start-up (its first block is evaluated
-            // exactly and tau restarts), so chunks stay >= 4096 blocks while aiming at ~48 K wave tasks for load
-            // balance; only a launch that could not otherwise fill the chip (one small image) splits finer.
-            long long want = (49152 + base_waves - 1) / base_waves;
-            long long cap = g.Nd / 4096;
-            if (cap < 1) cap = 1;
-            long long nc = want < cap ? want : cap;
-            if (base_waves * nc < 4096) {
-                long long cap2 = g.Nd / 512;
-                if (cap2 < 1) cap2 = 1;
-                long long fill = (4096 + base_waves - 1) / base_waves;
-                nc = fill < cap2 ? fill : cap2;
-            }
-            nchunks = (int)(nc < 1 ? 1 : nc);
-        }
-        if (nchunks > g.Nd) nchunks = g.Nd;
-        int chunk_len = (g.Nd + nchunks - 1) / nchunks;
-        chunk_len = (chunk_len + 1) & ~1;              // even: the sweep consumes blocks in pairs
-        nchunks = (g.Nd + chunk_len - 1) / chunk_len;
-        if (nchunks * (g.n_iso / NC) > 65535) return fail(FIC_E_ARGUMENT, "too many chunks (%d)", nchunks);
-        if (fic_launch_sweep_fast(c->b, g, tile0, ntiles, chunk_len, nchunks, s)) return fail(FIC_E_HIP, "k_sweep_fast launch failed");
     }
-    if (c->opt_time) {
-        HIP_TRY(hipEventRecord(e1, s));
-        c->ev.push_back(e0);
-        c->ev.push_back(e1);
-    }
+    if (rc == FIC_OK) rc = time_end(c, s);
+    if (rc != FIC_OK) return rc;
     c->last_chunks = nchunks;
     c->last_kind = kind;
     if (fic_launch_finalize(c->b, c->o, g, range_begin, range_count, s)) return fail(FIC_E_HIP, "k_finalize launch failed");
