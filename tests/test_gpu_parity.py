@@ -537,3 +537,22 @@ def test_near_tie_images(oracle, B, n_iso, density):
         for chunks in ((0, 3) if sweep >= 2 else (0,)):
             got = fic_amd.encode_gray(g, B, None, n_iso, sweep=sweep, chunks=chunks)
             _assert_same(oracle, got, ref)
+
+
+def test_sharded_encoder_wrapper_single_rank(oracle):
+    """ShardedEncoder without an initialised process group == one rank owning every range block."""
+    import torch
+    g = IMAGES["S256"]
+    ref = _oracle_encode(oracle, g, 8, 61, 8)
+    enc = fic_amd.ShardedEncoder(256, 256, 8, None, 8, planes=1, device=0)
+    try:
+        assert enc.world == 1 and enc.spans == [(0, 1024)]
+        enc.set_gray(torch.from_numpy(g.copy()).cuda().view(1, 256, 256))
+        enc.encode_local(torch.cuda.current_stream())
+        got = enc.gather()
+    finally:
+        enc.close()
+    assert (got["idx_local"][0] == ref["info"][:, 0].astype(np.int32)).all()
+    assert (got["iso"][0] == ref["iso"]).all()
+    assert same_f32(got["a"][0], ref["info"][:, 1]) and same_f32(got["b"][0], ref["info"][:, 2])
+    assert (got["qrows"][0] == oracle.quantise_gray(ref["info"])).all()
