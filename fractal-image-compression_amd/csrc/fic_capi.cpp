@@ -300,8 +300,14 @@ int matrix_core_sweep(fic_ctx* c, int tile0, int tile1, hipStream_t s, int* nchu
         long long want = (4096 + base_wg - 1) / base_wg;                       // ~4 resident per CU x 256 CUs x 4
         long long cap = m.ndtiles / 256;                                       // >= 256 domain tiles per chunk: start-up < 10 %
         if (cap < 1) cap = 1;
-        nchunks = (int)(want < cap ? want : cap);
-        if (nchunks < 1) nchunks = 1;
+        long long nc = want < cap ? want : cap;
+        if (base_wg * nc < 1024) {                                             // one small image: fill the chip first,
+            long long cap2 = m.ndtiles / 32;                                   // even at a higher per-chunk start-up share
+            if (cap2 < 1) cap2 = 1;
+            long long fill = (1024 + base_wg - 1) / base_wg;
+            nc = fill < cap2 ? fill : cap2;
+        }
+        nchunks = (int)(nc < 1 ? 1 : nc);
     }
     if (nchunks > m.ndtiles) nchunks = m.ndtiles;
     const int tiles_per_chunk = (m.ndtiles + nchunks - 1) / nchunks;
@@ -497,7 +503,10 @@ int fic_ctx_encode(fic_ctx* c, int range_begin, int range_count, void* hip_strea
         // FIC_SWEEP=3 opts the whole process into the matrix-core sweep wherever it is built (same results);
         // other geometries keep the VALU sweep.  An explicit fic_ctx_set_option("sweep", ...) wins.
         const char* env = getenv("FIC_SWEEP");
-        if (env && env[0] == '3' && env[1] == '\0' && g.full) kind = 3;
+        // Below ~5e8 (range, domain) pairs per launch (one 512x512 image: 6.4e7) the VALU sweep is faster: the
+        // matrix-core kernels' per-chunk start-up does not amortise (measured 0.45 vs 0.70 ms), so keep it there.
+        const long long pairs = (long long)g.planes * range_count * g.Nd;
+        if (env && env[0] == '3' && env[1] == '\0' && g.full && pairs >= 500000000LL) kind = 3;
     }
     if (kind >= 2 && !g.full) return fail(FIC_E_ARGUMENT, "fast sweep needs full search (wK == Dw == Dh)");
 

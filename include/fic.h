@@ -158,9 +158,10 @@ FIC_API int fic_ctx_decode_host(fic_ctx* ctx, uint8_t* gray_out, float* avg_erro
 
 /* Tuning / instrumentation knobs:
  *   "sweep"       0 auto (VALU fast kernel for full search, generic otherwise), 1 generic, 2 fast,
- *                 3 = opt-in matrix-core sweep (B = 8, n_iso = 8, full search; same results)
- *                 (with "sweep" = 0 the environment variable FIC_SWEEP=3 selects it process-wide wherever
- *                 it is built; other geometries keep the VALU sweep)
+ *                 3 = opt-in matrix-core sweep (B = 4/8/16, n_iso = 1 or 8, full search; same results)
+ *                 (with "sweep" = 0 the environment variable FIC_SWEEP=3 selects it process-wide for full-search
+ *                 launches of >= 5e8 (range, domain) pairs; smaller launches and windowed search keep the
+ *                 VALU sweep, which is faster there)
  *   "chunks"      domain-pool chunks per range tile for the fast kernel (0 = auto)
  *   "time_sweep"  1: bracket every sweep launch with hipEvents on its stream */
 FIC_API int fic_ctx_set_option(fic_ctx* ctx, const char* name, int value);

@@ -122,26 +122,27 @@ def test_mfma1_equals_valu_sweep_at_scale_and_sharded(B, size):
 
 
 def test_fic_sweep_environment_opt_in(tmp_path):
-    """FIC_SWEEP=3 selects the matrix-core sweep process-wide where it exists, and nothing else changes."""
+    """FIC_SWEEP=3 selects the matrix-core sweep process-wide for launches with enough work (>= 5e8 range x domain
+    pairs), leaves small launches on the VALU sweep (faster there), and nothing else changes."""
     import subprocess
     import sys
     code = (
         "import sys, numpy as np; sys.path.insert(0, %r); import fic_amd; from fic_amd import synth\n"
-        "g = synth.image_s(256, 256, 3)\n"
-        "out = {}\n"
-        "for B, n_iso in [(8, 8), (8, 1), (16, 8)]:\n"
-        "    with fic_amd.Encoder(256, 256, B, None, n_iso) as e:\n"
-        "        e.set_gray(g); e.encode(); r = e.results(); out[(B, n_iso)] = (e.info()['sweep_kind'], r['qrows'][0], r['iso'][0])\n"
-        "np.save(sys.argv[1], np.array([out[k][0] for k in sorted(out)]))\n"
-        "np.save(sys.argv[2], np.concatenate([out[k][1].ravel() for k in sorted(out)] + [out[k][2] for k in sorted(out)]))\n"
+        "out = []\n"
+        "for size, planes, B, n_iso in [(256, 1, 8, 8), (1024, 1, 8, 8), (1024, 1, 8, 1), (1024, 8, 16, 8)]:\n"
+        "    g = np.stack([synth.image_s(size, size, 3 + p) for p in range(planes)])\n"
+        "    with fic_amd.Encoder(size, size, B, None, n_iso, planes) as e:\n"
+        "        e.set_gray(g); e.encode(); r = e.results(); out.append((e.info()['sweep_kind'], r['qrows'].ravel(), r['iso'].ravel()))\n"
+        "np.save(sys.argv[1], np.array([o[0] for o in out]))\n"
+        "np.save(sys.argv[2], np.concatenate([o[1] for o in out] + [o[2] for o in out]))\n"
     ) % os.path.dirname(os.path.dirname(GOLDEN))
     res = {}
     for tag, env in (("valu", {}), ("mfma", {"FIC_SWEEP": "3"})):
         k, q = str(tmp_path / f"k_{tag}.npy"), str(tmp_path / f"q_{tag}.npy")
         subprocess.check_call([sys.executable, "-c", code, k, q], env={**os.environ, **env})
         res[tag] = (np.load(k), np.load(q))
-    assert res["valu"][0].tolist() == [2, 2, 2]
-    assert res["mfma"][0].tolist() == [3, 3, 3]          # every full-search configuration has a matrix-core sweep
+    assert res["valu"][0].tolist() == [2, 2, 2, 2]
+    assert res["mfma"][0].tolist() == [2, 3, 3, 3]       # the single 256x256 image stays on the VALU sweep
     assert (res["valu"][1] == res["mfma"][1]).all()
 
 
