@@ -98,6 +98,7 @@ struct fic_ctx {
     void* mfma_rngA = nullptr;
     void* mfma_sw = nullptr;
     int* mfma_rconst = nullptr;
+    int mfma_bf16 = 0;               // operand type the fragment stores were built for
     bool have_input = false;
     bool encoded_any = false;
     hipStream_t last_stream = nullptr;
@@ -244,40 +245,53 @@ int valu_sweep(fic_ctx* c, int tile0, int ntiles, hipStream_t s, int* nchunks_ou
 // Opt-in matrix-core sweeps: geometry of the fragment stores.
 struct MatrixCoreShape {
     bool iso8;
-    int NM;                          // K = 32 MFMA steps per block
+    bool bf16;                       // bf16 operands (B = 4 / 8 unless "sweep" = 4), else i8 operands
+    int steps;                       // MFMA steps per block: K = 16 (bf16) or K = 32 (i8)
     int ndtiles, ndtiles_alloc;      // domain tiles (x32 blocks), + 1 spare for the prefetch
     int nctiles_alloc;               // n_iso = 1: column tiles (x32 ranges), padded for the last workgroup
     int G8, ngroups8;                // n_iso = 8: range blocks per workgroup, number of groups
+    int ct1;                         // n_iso = 1: column tiles per workgroup
 };
-MatrixCoreShape matrix_core_shape(const FicGeom& g)
+MatrixCoreShape matrix_core_shape(const FicGeom& g, int kind)
 {
     MatrixCoreShape m;
     m.iso8 = g.n_iso == 8;
-    m.NM = g.n <= 32 ? 1 : g.n / 32;
+    m.bf16 = kind == 3 && g.B <= 8;
+    m.steps = m.bf16 ? fic_bf16_steps(g.B) : (g.n <= 32 ? 1 : g.n / 32);
     m.ndtiles = (g.Nd + 31) / 32;
     m.ndtiles_alloc = m.ndtiles + 1;
     m.nctiles_alloc = g.Nr_pad / 32 + 32;
-    m.G8 = fic_mfma8_group(g.B);
+    m.G8 = m.bf16 ? fic_bf16_group8() : fic_mfma8_group(g.B);
     m.ngroups8 = (g.Nr_pad + m.G8 - 1) / m.G8;
+    m.ct1 = m.bf16 ? fic_bf16_ct1() : fic_mfma1_ct(g.B);
     return m;
 }
-int matrix_core_prep(fic_ctx* c, hipStream_t s)
+int matrix_core_prep(fic_ctx* c, int kind, hipStream_t s)
 {
     const FicGeom& g = c->g;
-    const MatrixCoreShape m = matrix_core_shape(g);
+    const MatrixCoreShape m = matrix_core_shape(g, kind);
     const size_t P = (size_t)g.planes;
-    if (!c->mfma_poolB) {
-        HIP_TRY(hipMalloc(&c->mfma_poolB, P * m.ndtiles_alloc * m.NM * 64 * 16));
-        if (m.iso8) {
-            HIP_TRY(hipMalloc(&c->mfma_rngA, P * m.ngroups8 * (m.G8 / 4) * m.NM * 64 * 16));   // 32 KiB per group
-            HIP_TRY(hipMalloc((void**)&c->mfma_rconst, P * m.ngroups8 * (m.G8 / 4) * 16 * sizeof(int)));
-        } else {
-            HIP_TRY(hipMalloc(&c->mfma_sw, P * m.ndtiles_alloc * 32 * 8));
-            HIP_TRY(hipMalloc(&c->mfma_rngA, P * m.nctiles_alloc * m.NM * 64 * 16));
-            HIP_TRY(hipMalloc((void**)&c->mfma_rconst, P * m.nctiles_alloc * 32 * 16));
-        }
+    if (c->mfma_poolB && c->mfma_bf16 != (int)m.bf16) {     // operand type changed ("sweep" 3 <-> 4): new fragment stores
+        HIP_TRY(hipStreamSynchronize(s));
+        void* old[] = {c->mfma_poolB, c->mfma_rngA, c->mfma_sw, c->mfma_rconst};
+        for (void* p : old) if (p) (void)hipFree(p);
+        c->mfma_poolB = c->mfma_rngA = c->mfma_sw = nullptr;
+        c->mfma_rconst = nullptr;
     }
-    if (m.iso8) {
+    if (!c->mfma_poolB) {
+        c->mfma_bf16 = (int)m.bf16;
+        const size_t rtiles = m.iso8 ? (size_t)m.ngroups8 * (m.G8 / 4) : (size_t)m.nctiles_alloc;   // 32-row/column range tiles
+        HIP_TRY(hipMalloc(&c->mfma_poolB, P * m.ndtiles_alloc * m.steps * 64 * 16));
+        HIP_TRY(hipMalloc(&c->mfma_rngA, P * rtiles * m.steps * 64 * 16));
+        HIP_TRY(hipMalloc(&c->mfma_sw, P * m.ndtiles_alloc * 32 * 8));
+        if (!m.bf16)
+            HIP_TRY(hipMalloc((void**)&c->mfma_rconst, m.iso8 ? P * rtiles * 16 * sizeof(int) : P * rtiles * 32 * 16));
+    }
+    if (m.bf16) {
+        const int rtiles = m.iso8 ? m.ngroups8 * (m.G8 / 4) : m.nctiles_alloc;
+        if (fic_launch_bf16_prep(c->b, c->mfma_poolB, c->mfma_sw, c->mfma_rngA, g, m.ndtiles_alloc, rtiles, s))
+            return fail(FIC_E_HIP, "bf16 fragment prep launch failed");
+    } else if (m.iso8) {
         if (fic_launch_mfma_prep_pool(c->b.pool_pix, c->mfma_poolB, g, m.ndtiles_alloc, s) ||
             fic_launch_mfma_prep_range(c->b.rng_pix, c->b.rng_st, c->mfma_rngA, c->mfma_rconst, g, m.ngroups8, s))
             return fail(FIC_E_HIP, "mfma prep launch failed");
@@ -287,15 +301,15 @@ int matrix_core_prep(fic_ctx* c, hipStream_t s)
     }
     return FIC_OK;
 }
-int matrix_core_sweep(fic_ctx* c, int tile0, int tile1, hipStream_t s, int* nchunks_out)
+int matrix_core_sweep(fic_ctx* c, int kind, int tile0, int tile1, hipStream_t s, int* nchunks_out)
 {
     const FicGeom& g = c->g;
-    const MatrixCoreShape m = matrix_core_shape(g);
+    const MatrixCoreShape m = matrix_core_shape(g, kind);
     const int tsz = 64 * g.NR;
     int nchunks = c->opt_chunks;
     if (nchunks <= 0) {
         const long long ranges = (long long)(tile1 - tile0) * tsz;
-        const long long per_wg = m.iso8 ? m.G8 : 32LL * fic_mfma1_ct(g.B);
+        const long long per_wg = m.iso8 ? m.G8 : 32LL * m.ct1;
         const long long base_wg = (ranges + per_wg - 1) / per_wg * g.planes;   // workgroups per chunk
         long long want = (4096 + base_wg - 1) / base_wg;                       // ~4 resident per CU x 256 CUs x 4
         long long cap = m.ndtiles / 256;                                       // >= 256 domain tiles per chunk: start-up < 10 %
@@ -314,14 +328,19 @@ int matrix_core_sweep(fic_ctx* c, int tile0, int tile1, hipStream_t s, int* nchu
     nchunks = (m.ndtiles + tiles_per_chunk - 1) / tiles_per_chunk;
     if (m.iso8) {
         const int g0 = (tile0 * tsz) / m.G8, g1 = (tile1 * tsz + m.G8 - 1) / m.G8;   // groups covering the tile span
-        if (fic_launch_sweep_mfma(c->b, c->mfma_poolB, c->mfma_rngA, c->mfma_rconst, g, m.ngroups8, g0, g1 - g0, m.ndtiles,
-                                  m.ndtiles_alloc, tiles_per_chunk, nchunks, s))
-            return fail(FIC_E_HIP, "k_sweep_mfma launch failed");
+        const int rc = m.bf16 ? fic_launch_sweep_bf16(c->b, c->mfma_poolB, c->mfma_sw, c->mfma_rngA, g, m.ngroups8 * (m.G8 / 4), g0,
+                                                      g1 - g0, m.ndtiles, m.ndtiles_alloc, tiles_per_chunk, nchunks, s)
+                              : fic_launch_sweep_mfma(c->b, c->mfma_poolB, c->mfma_rngA, c->mfma_rconst, g, m.ngroups8, g0,
+                                                      g1 - g0, m.ndtiles, m.ndtiles_alloc, tiles_per_chunk, nchunks, s);
+        if (rc) return fail(FIC_E_HIP, "8-isometry matrix-core sweep launch failed");
     } else {
         const int ct_begin = tile0 * (tsz / 32), ct_end = tile1 * (tsz / 32);
-        if (fic_launch_sweep_mfma1(c->b, c->mfma_poolB, c->mfma_sw, c->mfma_rngA, c->mfma_rconst, g, ct_begin, ct_end,
-                                   m.ndtiles, m.ndtiles_alloc, m.nctiles_alloc, tiles_per_chunk, nchunks, s))
-            return fail(FIC_E_HIP, "k_sweep_mfma1 launch failed");
+        const int rc = m.bf16 ? fic_launch_sweep_bf16_1(c->b, c->mfma_poolB, c->mfma_sw, c->mfma_rngA, g, ct_begin, ct_end,
+                                                        m.ndtiles, m.ndtiles_alloc, m.nctiles_alloc, tiles_per_chunk, nchunks, s)
+                              : fic_launch_sweep_mfma1(c->b, c->mfma_poolB, c->mfma_sw, c->mfma_rngA, c->mfma_rconst, g, ct_begin,
+                                                       ct_end, m.ndtiles, m.ndtiles_alloc, m.nctiles_alloc, tiles_per_chunk,
+                                                       nchunks, s);
+        if (rc) return fail(FIC_E_HIP, "1-isometry matrix-core sweep launch failed");
     }
     *nchunks_out = nchunks;
     return FIC_OK;
@@ -519,13 +538,13 @@ int fic_ctx_encode(fic_ctx* c, int range_begin, int range_count, void* hip_strea
                              (size_t)ntiles * tsz * sizeof(unsigned long long), (size_t)g.planes, s));
     int nchunks = 1;
     int rc = FIC_OK;
-    if (kind == 3) rc = matrix_core_prep(c, s);              // fragment prep belongs to pool build / range prep: not timed
+    if (kind >= 3) rc = matrix_core_prep(c, kind, s);              // fragment prep belongs to pool build / range prep: not timed
     if (rc == FIC_OK) rc = time_begin(c, s);
     if (rc == FIC_OK) {
         if (kind == 1) {
             if (fic_launch_sweep_generic(c->b, g, range_begin, range_count, s)) rc = fail(FIC_E_HIP, "k_sweep_generic launch failed");
-        } else if (kind == 3) {
-            rc = matrix_core_sweep(c, tile0, tile1, s, &nchunks);
+        } else if (kind >= 3) {
+            rc = matrix_core_sweep(c, kind, tile0, tile1, s, &nchunks);
         } else {
             rc = valu_sweep(c, tile0, tile1 - tile0, s, &nchunks);
         }
@@ -597,7 +616,8 @@ int fic_ctx_set_option(fic_ctx* c, const char* name, int value)
 {
     if (!c || !name) return fail(FIC_E_ARGUMENT, "fic_ctx_set_option: null argument");
     if (!strcmp(name, "sweep")) {
-        if (value < 0 || value > 3) return fail(FIC_E_ARGUMENT, "sweep must be 0 (auto), 1 (generic), 2 (fast, VALU) or 3 (matrix-core)");
+        if (value < 0 || value > 4)
+            return fail(FIC_E_ARGUMENT, "sweep must be 0 (auto), 1 (generic), 2 (fast, VALU), 3 (matrix-core) or 4 (matrix-core, i8 operands)");
         c->opt_sweep = value;
     } else if (!strcmp(name, "chunks")) {
         if (value < 0) return fail(FIC_E_ARGUMENT, "chunks must be >= 0");

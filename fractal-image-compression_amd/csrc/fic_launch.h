@@ -86,6 +86,18 @@ int fic_launch_mfma1_prep(const FicBuffers& b, void* poolA, void* pool_sw, void*
 int fic_launch_sweep_mfma1(const FicBuffers& b, const void* poolA, const void* pool_sw, const void* rngB,
                            const void* rconst, const FicGeom& g, int ct_begin, int ct_end, int ndtiles, int ndtiles_alloc,
                            int nctiles_alloc, int tiles_per_chunk, int nchunks, hipStream_t s);
+// bf16-operand matrix-core sweeps (fic_bf16.hip): "sweep" = 3 at B = 4 / 8
+int fic_bf16_steps(int B);           // MFMA steps of K = 16 per block
+int fic_bf16_group8(void);           // range blocks per workgroup, 8-isometry kernel
+int fic_bf16_ct1(void);              // column tiles (x32 ranges) per workgroup, 1-isometry kernel
+int fic_launch_bf16_prep(const FicBuffers& b, void* poolF, void* pool_w, void* rngF, const FicGeom& g, int ndtiles_alloc,
+                         int nrtiles_alloc, hipStream_t s);
+int fic_launch_sweep_bf16(const FicBuffers& b, const void* poolF, const void* pool_w, const void* rngF, const FicGeom& g,
+                          int nrtiles_alloc, int group0, int ngroups_launch, int ndtiles, int ndtiles_alloc, int tiles_per_chunk, int nchunks,
+                          hipStream_t s);
+int fic_launch_sweep_bf16_1(const FicBuffers& b, const void* poolF, const void* pool_w, const void* rngF, const FicGeom& g,
+                            int ct_begin, int ct_end, int ndtiles, int ndtiles_alloc, int nctiles_alloc, int tiles_per_chunk,
+                            int nchunks, hipStream_t s);
 int fic_launch_decode_iteration_rgb(int32_t* scaled, int32_t* image, const int32_t* qrows5, FicDecodeState* state,
                                     int counter, const FicGeom& g, hipStream_t s);
 

@@ -1,6 +1,6 @@
-"""The opt-in matrix-core sweep ("sweep" = 3, B = 8, n_iso = 8) is held to the same bar as the default
-VALU sweep: bit-identical codebooks against the oracle, and against k_sweep_fast at sizes the oracle
-cannot reach."""
+"""The opt-in matrix-core sweeps ("sweep" = 3: bf16 operands at B = 4/8 -- fic_bf16.hip -- and i8 operands at
+B = 16; "sweep" = 4: i8 operands at every block size -- fic_mfma.hip) are held to the same bar as the default VALU
+sweep: bit-identical codebooks against the oracle, and against k_sweep_fast at sizes the oracle cannot reach."""
 import os
 
 import numpy as np
@@ -182,3 +182,37 @@ def test_mfma_8iso_other_block_sizes_equal_valu_sweep_at_scale_and_sharded(B, si
             r = enc.results()
             parts.append({k: v[:, b:b + c].copy() for k, v in r.items()})
     _same({k: np.concatenate([p[k] for p in parts], axis=1) for k in parts[0]}, valu)
+
+
+# ---- "sweep" = 4: the i8-operand kernels at B = 4 / 8 (where "sweep" = 3 now runs the bf16-operand kernels) -----------
+
+@pytest.mark.parametrize("B,n_iso,size", [(4, 8, 256), (8, 8, 512), (4, 1, 256), (8, 1, 512), (16, 8, 512), (16, 1, 512)])
+def test_i8_and_bf16_operand_kernels_agree_on_one_context(B, n_iso, size):
+    """One context, the sweeps switched back and forth (the fragment stores are rebuilt when the operand type
+    changes): VALU == matrix-core/bf16 == matrix-core/i8, bit for bit."""
+    imgs = np.stack([synth.image_u(size, size, 41 + B), synth.image_s(size, size, 42 + B)])
+    res = {}
+    with fic_amd.Encoder(size, size, B, None, n_iso, planes=2) as enc:
+        enc.set_gray(imgs)
+        for i, sweep in enumerate((2, 3, 4, 3)):
+            enc.set_option("sweep", sweep)
+            enc.encode()
+            res[i] = {k: v.copy() for k, v in enc.results().items()}
+            assert enc.info()["sweep_kind"] == sweep
+    for i in (1, 2, 3):
+        _same(res[0], res[i])
+
+
+@pytest.mark.parametrize("name", ["lena64", "S128", "U200"])
+@pytest.mark.parametrize("n_iso", [1, 8])
+def test_i8_operand_kernels_match_oracle(oracle, name, n_iso):
+    g = IMAGES[name]
+    h, w = g.shape
+    for B in (4, 8):
+        Dw = fic_amd.geometry(w, h, B)[2]
+        ref = oracle.encode_gray(oracle.gray_to_argb(g), w, h, B, Dw, n_iso)
+        got = fic_amd.encode_gray(g, B, None, n_iso, sweep=4, chunks=2)
+        assert (got["idx_local"] == ref["info"][:, 0].astype(np.int32)).all()
+        assert (got["iso"] == ref["iso"]).all()
+        assert (got["qrows"] == oracle.quantise_gray(ref["info"])).all()
+        assert same_f32(got["err"], ref["err"])
