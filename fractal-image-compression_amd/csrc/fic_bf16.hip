@@ -26,6 +26,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <math.h>
+#include <type_traits>
 #include "fic_device.h"
 #include "fic_launch.h"
 #include "fic_devfn.h"
@@ -34,6 +35,10 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 typedef float v16f __attribute__((ext_vector_type(16)));
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+// Level of a pair as the sweeps raise tau with it: the tested product |cov| * fl(1/s32) times (1 - 2^-17).  It is below
+// the pair's true |cov| / sqrt(var) by at least 2^-18 relative (the product carries < 2^-22 of rounding), so a later
+// pair whose tested product does not exceed it has a strictly smaller |r| -- the invariant of DESIGN.md section 4.2.
+#define FIC_BF16_LEVEL 0.99999237060546875f
 #define FIC_TAU_ALL 8192.0f                // > |cov| / sqrt(var) for any pair (|cov| <= sqrt(n)*255*sqrt(var) <= 4080*sqrt(var))
 
 // two integers in [-255, 255] -> two bf16 (exact: 8 significant bits), element 0 in the low half
@@ -141,20 +146,26 @@ __device__ __forceinline__ unsigned long long wave_min_key(unsigned long long k)
 //              range q = e>>2 -- so tau is wave-uniform per element group -- and isometry k = (e&3) + 4*(lane>>5).
 //              A wave keeps the fragments of its T = 4 row tiles in VGPRs for the whole sweep (no LDS traffic
 //              in the loop); a workgroup = 4 waves = 64 range blocks.
-//   cols (B) = 32 consecutive domain blocks, streamed from HBM/L2 (double-buffered in VGPRs); the four waves of a
-//              workgroup sweep the same pool chunk, so three of their four loads of a tile hit in L1.
+//   cols (B) = 32 consecutive domain blocks, streamed from HBM/L2 (two VGPR buffers, the loop is unrolled by two
+//              so they swap roles without moves); the four waves of a workgroup sweep the same pool chunk, so
+//              three of their four loads of a tile hit in L1.
 //   The MFMAs of the next tile are issued BEFORE the epilogue of the current one (two accumulator sets), so a
 //   single wave keeps the matrix pipe busy while its VALU works through the prune test.
-//   Prune test per pair (f32):  |cov| * fl(1/s32) > tau   (k_sweep_mfma1's form): two
-//   v_pk_mul_f32 + a max tree + one compare per range.  tau of a range is owned by one wave and lives in an SGPR.
-//   Exact path (rare, wave-uniform branch per range): the flagged lanes run the Java epilogue, the wave reduces
-//   their (error, candidate) keys and levels with DPP, ONE lane issues the 64-bit atomicMin, tau is raised in
-//   place -- no same-address atomics from 64 lanes (they cost 2 ms per pool chunk in the forced first tile).
+//   Prune test per pair (f32):  |cov| * fl(1/s32) > tau   (k_sweep_mfma1's form).
+//   tau of a range is owned by one wave and is wave-uniform.
+//   Flagged pairs (rare).  The kernel is VALU-issue bound, so the exact path is kept off the wave's instruction
+//   stream: a flagged pair raises tau at once (its level is the tested product times (1 - 2^-17), reduced over
+//   the wave with DPP) and is PUSHED -- covariance and candidate id, 8 bytes -- onto the wave's LDS
+//   queue; the Java epilogue (f64 divide, FC:677-683) and the 64-bit atomicMin run later, 64 queued pairs at a
+//   time, one per lane.  Every queued pair is evaluated before the wave exits, so raising tau on its behalf is the
+//   same invariant as before (tau never exceeds the level of an evaluated lower-index pair).
+//   The chunk's first domain tile is evaluated exactly in place (it initialises tau): keys and levels are reduced
+//   inside the wave and ONE lane issues the atomicMin per range -- 64 lanes hammering one address cost 2 ms per
+//   chunk here.
 // ---------------------------------------------------------------------------------------------
 struct Bf16Args {
     const v4i* poolF;                // [plane][ndtiles_alloc][NK][64]
     const float* pool_w;             // [plane][ndtiles_alloc][32]   fl(1/s32) per domain block (0: flat or padding)
-    const FicDomStat* pool_st;
     const double* pool_s64;
     const v4i* rngF;                 // [plane][nrtiles_alloc][NK][64]
     const FicRngStat* rng_st;
@@ -166,11 +177,14 @@ struct Bf16Args {
 };
 #define FIC_BF16_T 4                 // row tiles per wave
 #define FIC_BF16_RT 16               // row tiles per workgroup (64 range blocks)
+#define FIC_BF16_QCAP 1280           // queue entries per wave: one tile can flag at most 1024 pairs
+#define FIC_BF16_QFLUSH 256          // evaluate the queue before a tile's pushes once it holds this many
 
 template <int NK>
 __global__ __launch_bounds__(256) void k_sweep_bf16(Bf16Args A)
 {
     constexpr int T = FIC_BF16_T, RT = FIC_BF16_RT;
+    __shared__ uint2 sQ[4][FIC_BF16_QCAP];             // per wave: {covariance (f32 bits), candidate | range-in-wave << 27}
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     int combo_, gx_;                                   // XCD-aware 1-D grid: combo = (pool chunk, plane), x = range group
@@ -195,57 +209,93 @@ __global__ __launch_bounds__(256) void k_sweep_bf16(Bf16Args A)
     }
     // ranges with rem == 0: error 0 for every block (FC:677) -> nothing after the first tile can win
     float tau[T][4];
+    uint32_t remnz = 0;                                // bit 4t+q: rem != 0 (wave-uniform)
 #pragma unroll
     for (int t = 0; t < T; t++)
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             const int j = jw + 4 * t + q;
-            const int rem = __builtin_amdgcn_readfirstlane(j < A.Nr_pad ? rst[j].rem : 0);
+            const int rem = __builtin_amdgcn_readfirstlane(j < A.Nr ? rst[j].rem : 0);   // padding ranges: never flagged
             tau[t][q] = rem == 0 ? FIC_TAU_ALL : 0.0f;
+            remnz |= rem != 0 ? 1u << (4 * t + q) : 0u;
         }
 
     const int jcol = lane & 31, half = lane >> 5;
     const v4i* pb = A.poolF + (size_t)plane * A.ndtiles_alloc * NK * 64 + lane;
     const float* pw = A.pool_w + (size_t)plane * A.ndtiles_alloc * 32 + jcol;
-    const FicDomStat* pst = A.pool_st + (size_t)plane * A.Nd_pad;
     const double* p64 = A.pool_s64 + (size_t)plane * A.Nd_pad;
     unsigned long long* keyp = A.key + (size_t)plane * A.Nr_pad;
     const v16f zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    uint2* const myq = sQ[wave];
+    int qn = 0;                                        // queued pairs (wave-uniform)
 
-    // exact path for the accumulator tile of (row tile t, domain tile dt); p[e] = cov * w as tested
-    auto exact_tile = [&](const v16f& acc, const float (&p)[16], const bool (&flag)[4], int t, int dt, bool force) {
-        const int d = dt * 32 + jcol;
-        const bool valid = d < A.Nd;
+    // Java epilogue + atomicMin for the queued pairs, one per lane
+    auto flush = [&]() {
+        for (int base = 0; base < qn; base += 64) {
+            const int i = base + lane;
+            if (i < qn) {
+                const uint2 ent = myq[i];
+                const int cov = (int)__uint_as_float(ent.x);
+                const uint32_t cand = ent.y & 0x07FFFFFFu;
+                const int j = jw + (int)(ent.y >> 27);
+                const float err = exact_error(cov, rst[j].rem, p64[cand >> 3]);
+                atomicMin(&keyp[j], ((unsigned long long)f32_orderable(err) << 32) | cand);
+            }
+        }
+        qn = 0;
+    };
+    // a tile with flagged pairs (p[e] = cov * w as tested): raise tau, queue the pairs
+    auto flagged_tile = [&](const v16f& acc, const float (&p)[16], const bool (&flag)[4], int t, int dt) {
+        if (qn > FIC_BF16_QFLUSH) flush();
+        const uint32_t d8 = (uint32_t)(dt * 32 + jcol) * 8u + (uint32_t)(4 * half);
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             const int j = jw + 4 * t + q;                              // wave-uniform
-            const bool on = (flag[q] || force) && valid && j < A.Nr;
-            if (!__any(on)) continue;
-            const int rem = rst[j].rem;
-            const double s64 = on ? p64[d] : 0.0;
-            unsigned long long best = FIC_KEY_NONE;
-            float mc = 0.0f;                                           // largest |cov| evaluated on this lane
+            if (__builtin_amdgcn_ballot_w64(flag[q]) == 0 || j >= A.Nr) continue;
+            float mp = 0.0f;                                           // largest flagged |cov * w| on this lane
 #pragma unroll
             for (int ee = 0; ee < 4; ee++) {
                 const int e = 4 * q + ee;
-                if (on && (force || fabsf(p[e]) > tau[t][q])) {
-                    const int cov = (int)acc[e];
+                const bool pe = fabsf(p[e]) > tau[t][q];               // implies a valid, non-flat block (w > 0)
+                const unsigned long long be = __builtin_amdgcn_ballot_w64(pe);
+                if (be == 0) continue;
+                const int idx = qn + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(be >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)be, 0u));
+                if (pe) {
+                    myq[idx] = make_uint2(__float_as_uint(acc[e]), (d8 + (uint32_t)ee) | ((uint32_t)(4 * t + q) << 27));
+                    mp = fmaxf(mp, fabsf(p[e]));
+                }
+                qn += __builtin_popcountll(be);
+            }
+            const float lmax = __uint_as_float(wave_reduce_u32<true>(__float_as_uint(__fmul_rn(mp, FIC_BF16_LEVEL))));   // >= 0: uint order == float order
+            if (remnz & (1u << (4 * t + q))) tau[t][q] = fmaxf(tau[t][q], lmax);
+        }
+    };
+    // the chunk's first domain tile: every pair evaluated exactly, in place
+    auto forced_tile = [&](const v16f& acc, int t, int dt, float w) {
+        const int d = dt * 32 + jcol;
+        const bool valid = d < A.Nd;
+        const double s64 = valid ? p64[d] : 0.0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int j = jw + 4 * t + q;                              // wave-uniform
+            if (j >= A.Nr) continue;
+            const int rem = rst[j].rem;
+            unsigned long long best = FIC_KEY_NONE;
+            float mp = 0.0f;
+            if (valid) {
+#pragma unroll
+                for (int ee = 0; ee < 4; ee++) {
+                    const int cov = (int)acc[4 * q + ee];
                     const float err = exact_error(cov, rem, s64);
                     const unsigned long long k = ((unsigned long long)f32_orderable(err) << 32) |
                                                  ((uint32_t)d * 8u + (uint32_t)(ee + 4 * half));
                     best = k < best ? k : best;
-                    mc = fmaxf(mc, fabsf((float)cov));
+                    mp = fmaxf(mp, fabsf(__fmul_rn(acc[4 * q + ee], w)));
                 }
             }
-            // one atomic per (wave, range); the level of the lane's largest |cov| is the lane's largest level
-            const unsigned long long kmin = wave_min_key(best);
+            const unsigned long long kmin = wave_min_key(best);        // one atomic per (wave, range)
             if (lane == 0 && kmin != FIC_KEY_NONE) atomicMin(&keyp[j], kmin);
-            float lvl = 0.0f;
-            if (mc > 0.0f) {
-                const float s32 = pst[d].s32;                          // mc > 0 implies a valid, evaluated block
-                lvl = (s32 == 0.0f) ? 0.0f : __fmul_rn(__fdiv_rn(mc, s32), 0.99999618530273437500f);
-            }
-            const float lmax = __uint_as_float(wave_reduce_u32<true>(__float_as_uint(lvl)));   // lvl >= 0: uint order == float order
+            const float lmax = __uint_as_float(wave_reduce_u32<true>(__float_as_uint(__fmul_rn(mp, FIC_BF16_LEVEL))));
             if (rem != 0) tau[t][q] = fmaxf(tau[t][q], lmax);
         }
     };
@@ -256,46 +306,54 @@ __global__ __launch_bounds__(256) void k_sweep_bf16(Bf16Args A)
         return acc;
     };
 
-    v4i b[NK], nb[NK];
+    v4i b0[NK], b1[NK];
 #pragma unroll
-    for (int m = 0; m < NK; m++) b[m] = pb[((size_t)dt0 * NK + m) * 64];
+    for (int m = 0; m < NK; m++) b0[m] = pb[((size_t)dt0 * NK + m) * 64];
     float w = pw[(size_t)dt0 * 32];
-    v16f acc = tile_mfma(a[0], b);
-    for (int dt = dt0; dt < dt1; dt++) {
-        // prefetch the next domain tile (the fragment store has one spare tile)
+    v16f acc = tile_mfma(a[0], b0);
+
+    // one domain tile: bc = its fragments, bn = buffer for the next tile's (the fragment store has one spare tile)
+    auto step = [&](auto forced, int dt, const v4i (&bc)[NK], v4i (&bn)[NK]) {
+        constexpr bool FORCE = decltype(forced)::value;
 #pragma unroll
-        for (int m = 0; m < NK; m++) nb[m] = pb[((size_t)(dt + 1) * NK + m) * 64];
+        for (int m = 0; m < NK; m++) bn[m] = pb[((size_t)(dt + 1) * NK + m) * 64];
         const float nw = pw[(size_t)(dt + 1) * 32];
-        const bool force = (dt == dt0);                 // wave-uniform: the chunk's first tile initialises tau
-        const v2f ww = {w, w};
 #pragma unroll
         for (int t = 0; t < T; t++) {
             // issue the next tile's MFMAs first: (t+1, dt), or (0, dt+1) on the prefetched fragments
             v16f nacc;
-            if (t + 1 < T) nacc = tile_mfma(a[t + 1], b);
-            else nacc = tile_mfma(a[0], nb);
-            // acc[e] = kovarianz of (range 4t+q copy k, domain d), exact
-            float p[16];
+            if (t + 1 < T) nacc = tile_mfma(a[t + 1], bc);
+            else nacc = tile_mfma(a[0], bn);
+            if constexpr (FORCE) {
+                forced_tile(acc, t, dt, w);
+            } else {
+                // acc[e] = kovarianz of (range 4t+q copy k, domain d), exact
+                float p[16];
 #pragma unroll
-            for (int e = 0; e < 16; e += 2) {
-                const v2f pp = (v2f){acc[e], acc[e + 1]} * ww;         // v_pk_mul_f32; |fl(cov * w)| == fl(|cov| * w)
-                p[e] = pp.x; p[e + 1] = pp.y;
-            }
-            bool flag[4];
-            bool any = force;
+                for (int e = 0; e < 16; e++) p[e] = __fmul_rn(acc[e], w);   // |fl(cov * w)| == fl(|cov| * w)
+                bool flag[4];
+                bool any = false;
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const float mx = fmaxf(fmaxf(fabsf(p[4 * q]), fabsf(p[4 * q + 1])), fmaxf(fabsf(p[4 * q + 2]), fabsf(p[4 * q + 3])));
-                flag[q] = mx > tau[t][q];
-                any |= flag[q];
+                for (int q = 0; q < 4; q++) {
+                    const float mx = fmaxf(fmaxf(fabsf(p[4 * q]), fabsf(p[4 * q + 1])), fmaxf(fabsf(p[4 * q + 2]), fabsf(p[4 * q + 3])));
+                    flag[q] = mx > tau[t][q];
+                    any |= flag[q];
+                }
+                if (__builtin_expect(__builtin_amdgcn_ballot_w64(any) != 0, 0)) flagged_tile(acc, p, flag, t, dt);
             }
-            if (__builtin_expect(__any(any), 0)) exact_tile(acc, p, flag, t, dt, force);
             acc = nacc;
         }
-#pragma unroll
-        for (int m = 0; m < NK; m++) b[m] = nb[m];
         w = nw;
+    };
+    int dt = dt0;
+    step(std::true_type{}, dt, b0, b1);
+    dt++;
+    for (; dt + 1 < dt1; dt += 2) {
+        step(std::false_type{}, dt, b1, b0);
+        step(std::false_type{}, dt + 1, b0, b1);
     }
+    if (dt < dt1) step(std::false_type{}, dt, b1, b0);
+    flush();
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -303,17 +361,19 @@ __global__ __launch_bounds__(256) void k_sweep_bf16(Bf16Args A)
 //   rows (A) = 32 consecutive domain blocks, streamed; cols (B) = 32 range blocks; a wave keeps the fragments of
 //   its CTW = 4 column tiles in VGPRs; a workgroup = 16 column tiles = 512 range blocks.
 //   col = lane&31 is the lane's range block: its tau sits in one VGPR per column tile (LDS copy so that the two
-//   lane halves of a column see each other's updates: ds_max_u32 in the exact path, re-read afterwards).
+//   lane halves of a column see each other's updates: ds_max_u32 when a pair is flagged, re-read afterwards).
 //   row = (e&3) + 8(e>>2) + 4(lane>>5) is element e's domain block: w = fl(1/s32) of the lane's 16 rows comes as
 //   four 16-byte loads per domain tile (stored per tile in exactly that order by k_pool_bf16).
 // Prune test per pair (f32):  |cov| * fl(1/s32) > tau  -- k_sweep_mfma1's test.
-// As in k_sweep_bf16 the next tile's MFMAs are issued before the current tile's epilogue; the exact path keeps a
-// lane-local best key over the lane's 16 rows and issues one atomicMin per lane.
+// As in k_sweep_bf16: the next tile's MFMAs are issued before the current tile's epilogue; flagged pairs raise tau
+// at once and are queued in LDS, the Java epilogue and the atomicMin run later, one queued pair per lane (here
+// one tile in six flags something -- 128 range blocks per wave, a dozen records each -- so the deferred epilogue
+// matters more than in the 8-isometry kernel); the chunk's first domain tile is evaluated exactly in place, one
+// atomicMin per lane.
 // ---------------------------------------------------------------------------------------------
 struct Bf16Args1 {
     const v4i* poolF;
     const float* pool_w;             // [plane][ndtiles_alloc][2][16]
-    const FicDomStat* pool_st;
     const double* pool_s64;
     const v4i* rngF;                 // [plane][nctiles_alloc][NK][64]
     const FicRngStat* rng_st;
@@ -332,6 +392,7 @@ __global__ __launch_bounds__(256) void k_sweep_bf16_1(Bf16Args1 A)
 {
     constexpr int CTW = FIC_BF16_CTW, CT = FIC_BF16_CT;
     __shared__ uint32_t sTau[CT * 32];
+    __shared__ uint2 sQ[4][FIC_BF16_QCAP];             // per wave: {covariance (f32 bits), domain block | range-in-wave << 24}
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     int combo_, gx_;
@@ -343,7 +404,7 @@ __global__ __launch_bounds__(256) void k_sweep_bf16_1(Bf16Args1 A)
     const FicRngStat* rst = A.rng_st + (size_t)plane * A.Nr_pad;
     for (int i = threadIdx.x; i < CT * 32; i += 256) {
         const int j = ct0 * 32 + i;
-        const int rem = j < A.Nr_pad ? rst[j].rem : 0;
+        const int rem = j < A.Nr ? rst[j].rem : 0;                 // padding ranges: never flagged
         sTau[i] = rem == 0 ? __float_as_uint(FIC_TAU_ALL) : 0u;   // rem == 0: nothing after the first block can win
     }
     v4i rb[CTW][NK];
@@ -364,41 +425,83 @@ __global__ __launch_bounds__(256) void k_sweep_bf16_1(Bf16Args1 A)
 
     const int jcol = lane & 31, half = lane >> 5;
     float tau[CTW];
+    uint32_t raise = 0;                                      // bit ci: this lane's range block has rem != 0 and exists
 #pragma unroll
-    for (int ci = 0; ci < CTW; ci++) tau[ci] = __uint_as_float(sTau[(wave * CTW + ci) * 32 + jcol]);
+    for (int ci = 0; ci < CTW; ci++) {
+        const uint32_t t0 = sTau[(wave * CTW + ci) * 32 + jcol];
+        tau[ci] = __uint_as_float(t0);
+        raise |= (t0 == 0u && (ctw0 + ci) * 32 + jcol < A.Nr) ? 1u << ci : 0u;
+    }
 
     const v4i* pa = A.poolF + (size_t)plane * A.ndtiles_alloc * NK * 64 + lane;
     const float4* pw = (const float4*)(A.pool_w + (size_t)plane * A.ndtiles_alloc * 32) + half * 4;
-    const FicDomStat* pst = A.pool_st + (size_t)plane * A.Nd_pad;
     const double* p64 = A.pool_s64 + (size_t)plane * A.Nd_pad;
     unsigned long long* keyp = A.key + (size_t)plane * A.Nr_pad;
     const v16f zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    uint2* const myq = sQ[wave];
+    int qn = 0;                                              // queued pairs (wave-uniform)
 
-    auto exact_tile = [&](const v16f& acc, const float (&p)[16], bool any, int ci, int dt, bool force) {
-        const int j = (ctw0 + ci) * 32 + jcol;               // the lane's range block
-        if (j < A.Nr && (any || force)) {
+    // Java epilogue + atomicMin for the queued pairs, one per lane
+    auto flush = [&]() {
+        for (int base = 0; base < qn; base += 64) {
+            const int i = base + lane;
+            if (i < qn) {
+                const uint2 ent = myq[i];
+                const int cov = (int)__uint_as_float(ent.x);
+                const uint32_t d = ent.y & 0x00FFFFFFu;
+                const int j = ctw0 * 32 + (int)(ent.y >> 24);
+                const float err = exact_error(cov, rst[j].rem, p64[d]);
+                atomicMin(&keyp[j], ((unsigned long long)f32_orderable(err) << 32) | d);
+            }
+        }
+        qn = 0;
+    };
+    // publish a lane's new level for its range block and pick up the other lane half's
+    auto raise_tau = [&](int ci, float mp) {
+        const uint32_t lb = __float_as_uint(__fmul_rn(mp, FIC_BF16_LEVEL));     // >= 0: uint order == float order
+        if (((raise >> ci) & 1u) && lb != 0u) atomicMax(&sTau[(wave * CTW + ci) * 32 + jcol], lb);
+        tau[ci] = __uint_as_float(sTau[(wave * CTW + ci) * 32 + jcol]);
+    };
+    // a tile with flagged pairs (p[e] = cov * w as tested): queue them, raise tau
+    auto flagged_tile = [&](const v16f& acc, const float (&p)[16], int ci, int dt) {
+        if (qn > FIC_BF16_QFLUSH) flush();
+        const bool lane_ok = (ctw0 + ci) * 32 + jcol < A.Nr;
+        const uint32_t tag = (uint32_t)(dt * 32 + 4 * half) | ((uint32_t)(ci * 32 + jcol) << 24);
+        float mp = 0.0f;                                     // largest flagged |cov * w| on this lane
+#pragma unroll
+        for (int e = 0; e < 16; e++) {
+            const bool pe = lane_ok && fabsf(p[e]) > tau[ci];                  // implies a real, non-flat block (w > 0)
+            const unsigned long long be = __builtin_amdgcn_ballot_w64(pe);
+            if (be == 0) continue;
+            const int idx = qn + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(be >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)be, 0u));
+            if (pe) {
+                myq[idx] = make_uint2(__float_as_uint(acc[e]), tag + (uint32_t)((e & 3) + 8 * (e >> 2)));
+                mp = fmaxf(mp, fabsf(p[e]));
+            }
+            qn += __builtin_popcountll(be);
+        }
+        raise_tau(ci, mp);
+    };
+    // the chunk's first domain tile: every pair evaluated exactly, in place; one atomicMin per lane
+    auto forced_tile = [&](const v16f& acc, const float (&p)[16], int ci, int dt) {
+        const int j = (ctw0 + ci) * 32 + jcol;
+        float mp = 0.0f;
+        if (j < A.Nr) {
             const int rem = rst[j].rem;
             unsigned long long best = FIC_KEY_NONE;
-            uint32_t lbits = 0u;
 #pragma unroll
             for (int e = 0; e < 16; e++) {
                 const int d = dt * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
-                if ((force || fabsf(p[e]) > tau[ci]) && d < A.Nd) {
-                    const int cov = (int)acc[e];
-                    const float err = exact_error(cov, rem, p64[d]);
+                if (d < A.Nd) {
+                    const float err = exact_error((int)acc[e], rem, p64[d]);
                     const unsigned long long k = ((unsigned long long)f32_orderable(err) << 32) | (uint32_t)d;
                     best = k < best ? k : best;
-                    const float s32 = pst[d].s32;
-                    const float lvl = (s32 == 0.0f) ? 0.0f
-                                                    : __fmul_rn(__fdiv_rn(fabsf((float)cov), s32), 0.99999618530273437500f);
-                    const uint32_t lb = __float_as_uint(lvl);
-                    lbits = lb > lbits ? lb : lbits;         // lvl >= 0: uint order == float order
+                    mp = fmaxf(mp, fabsf(p[e]));
                 }
             }
             if (best != FIC_KEY_NONE) atomicMin(&keyp[j], best);
-            if (rem != 0 && lbits != 0u) atomicMax(&sTau[(wave * CTW + ci) * 32 + jcol], lbits);
         }
-        tau[ci] = __uint_as_float(sTau[(wave * CTW + ci) * 32 + jcol]);   // both lane halves of the column
+        raise_tau(ci, mp);
     };
     auto tile_mfma = [&](const v4i (&at)[NK], const v4i (&bt)[NK]) {
         v16f acc = zero;
@@ -407,44 +510,53 @@ __global__ __launch_bounds__(256) void k_sweep_bf16_1(Bf16Args1 A)
         return acc;
     };
 
-    v4i a[NK], na[NK];
+    v4i a0[NK], a1[NK];
 #pragma unroll
-    for (int m = 0; m < NK; m++) a[m] = pa[((size_t)dt0 * NK + m) * 64];
-    v16f acc = tile_mfma(a, rb[0]);
-    for (int dt = dt0; dt < dt1; dt++) {
+    for (int m = 0; m < NK; m++) a0[m] = pa[((size_t)dt0 * NK + m) * 64];
+    v16f acc = tile_mfma(a0, rb[0]);
+
+    // one domain tile: ac = its fragments, an = buffer for the next tile's (the fragment store has one spare tile)
+    auto step = [&](auto forced, int dt, const v4i (&ac)[NK], v4i (&an)[NK]) {
+        constexpr bool FORCE = decltype(forced)::value;
 #pragma unroll
-        for (int m = 0; m < NK; m++) na[m] = pa[((size_t)(dt + 1) * NK + m) * 64];   // one spare tile in the store
+        for (int m = 0; m < NK; m++) an[m] = pa[((size_t)(dt + 1) * NK + m) * 64];
         float w[16];
 #pragma unroll
         for (int v = 0; v < 4; v++) {
             const float4 w4 = pw[(size_t)dt * 8 + v];
             w[4 * v] = w4.x; w[4 * v + 1] = w4.y; w[4 * v + 2] = w4.z; w[4 * v + 3] = w4.w;
         }
-        const bool force = (dt == dt0);                      // wave-uniform
 #pragma unroll
         for (int ci = 0; ci < CTW; ci++) {
             // issue the next tile's MFMAs first: column tile ci+1 of this domain tile, or column tile 0 of the next
             v16f nacc;
-            if (ci + 1 < CTW) nacc = tile_mfma(a, rb[ci + 1]);
-            else nacc = tile_mfma(na, rb[0]);
+            if (ci + 1 < CTW) nacc = tile_mfma(ac, rb[ci + 1]);
+            else nacc = tile_mfma(an, rb[0]);
             if (ci < nci) {                                  // wave-uniform
-                float p[16];                                 // |fl(cov * w)| == fl(|cov| * w); v_pk_mul_f32 pairs
+                float p[16];
 #pragma unroll
-                for (int e = 0; e < 16; e += 2) {
-                    const v2f pp = (v2f){acc[e], acc[e + 1]} * (v2f){w[e], w[e + 1]};
-                    p[e] = pp.x; p[e + 1] = pp.y;
+                for (int e = 0; e < 16; e++) p[e] = __fmul_rn(acc[e], w[e]);   // |fl(cov * w)| == fl(|cov| * w)
+                if constexpr (FORCE) {
+                    forced_tile(acc, p, ci, dt);
+                } else {
+                    float mx = fabsf(p[0]);
+#pragma unroll
+                    for (int e = 1; e < 16; e++) mx = fmaxf(mx, fabsf(p[e]));
+                    if (__builtin_expect(__builtin_amdgcn_ballot_w64(mx > tau[ci]) != 0, 0)) flagged_tile(acc, p, ci, dt);
                 }
-                float mx = fabsf(p[0]);
-#pragma unroll
-                for (int e = 1; e < 16; e++) mx = fmaxf(mx, fabsf(p[e]));
-                const bool any = mx > tau[ci];
-                if (__builtin_expect(__any(any || force), 0)) exact_tile(acc, p, any, ci, dt, force);
             }
             acc = nacc;
         }
-#pragma unroll
-        for (int m = 0; m < NK; m++) a[m] = na[m];
+    };
+    int dt = dt0;
+    step(std::true_type{}, dt, a0, a1);
+    dt++;
+    for (; dt + 1 < dt1; dt += 2) {
+        step(std::false_type{}, dt, a1, a0);
+        step(std::false_type{}, dt + 1, a0, a1);
     }
+    if (dt < dt1) step(std::false_type{}, dt, a1, a0);
+    flush();
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -475,13 +587,13 @@ int fic_launch_sweep_bf16(const FicBuffers& b, const void* poolF, const void* po
                           hipStream_t s)
 {
     Bf16Args A;
-    A.poolF = (const v4i*)poolF; A.pool_w = (const float*)pool_w; A.pool_st = b.pool_st; A.pool_s64 = b.pool_s64;
+    A.poolF = (const v4i*)poolF; A.pool_w = (const float*)pool_w; A.pool_s64 = b.pool_s64;
     A.rngF = (const v4i*)rngF; A.rng_st = b.rng_st; A.key = b.key;
     A.Nd = g.Nd; A.Nd_pad = g.Nd_pad; A.Nr = g.Nr; A.Nr_pad = g.Nr_pad;
     A.ndtiles = ndtiles; A.ndtiles_alloc = ndtiles_alloc; A.nrtiles_alloc = nrtiles_alloc;
     A.group0 = group0; A.ngroups_launch = ngroups_launch; A.tiles_per_chunk = tiles_per_chunk; A.nchunks = nchunks;
     A.planes = g.planes;
-    if ((group0 + ngroups_launch) * FIC_BF16_RT > nrtiles_alloc) return (int)hipErrorInvalidValue;
+    if ((group0 + ngroups_launch) * FIC_BF16_RT > nrtiles_alloc || g.Nd >= (1 << 24)) return (int)hipErrorInvalidValue;
     dim3 grid((unsigned)(nchunks * g.planes) * (unsigned)ngroups_launch), block(256);
     if (g.B == 4) hipLaunchKernelGGL((k_sweep_bf16<1>), grid, block, 0, s, A);
     else if (g.B == 8) hipLaunchKernelGGL((k_sweep_bf16<4>), grid, block, 0, s, A);
@@ -495,14 +607,14 @@ int fic_launch_sweep_bf16_1(const FicBuffers& b, const void* poolF, const void* 
                             int nchunks, hipStream_t s)
 {
     Bf16Args1 A;
-    A.poolF = (const v4i*)poolF; A.pool_w = (const float*)pool_w; A.pool_st = b.pool_st; A.pool_s64 = b.pool_s64;
+    A.poolF = (const v4i*)poolF; A.pool_w = (const float*)pool_w; A.pool_s64 = b.pool_s64;
     A.rngF = (const v4i*)rngF; A.rng_st = b.rng_st; A.key = b.key;
     A.Nd = g.Nd; A.Nd_pad = g.Nd_pad; A.Nr = g.Nr; A.Nr_pad = g.Nr_pad;
     A.ndtiles = ndtiles; A.ndtiles_alloc = ndtiles_alloc; A.nctiles_alloc = nctiles_alloc;
     A.ct_begin = ct_begin; A.ct_end = ct_end; A.tiles_per_chunk = tiles_per_chunk; A.nchunks = nchunks;
     A.nctg = (ct_end - ct_begin + FIC_BF16_CT - 1) / FIC_BF16_CT;
     A.planes = g.planes;
-    if (ct_begin + A.nctg * FIC_BF16_CT > nctiles_alloc) return (int)hipErrorInvalidValue;
+    if (ct_begin + A.nctg * FIC_BF16_CT > nctiles_alloc || g.Nd >= (1 << 24)) return (int)hipErrorInvalidValue;
     dim3 grid((unsigned)(nchunks * g.planes) * (unsigned)A.nctg), block(256);
     if (g.B == 4) hipLaunchKernelGGL((k_sweep_bf16_1<1>), grid, block, 0, s, A);
     else if (g.B == 8) hipLaunchKernelGGL((k_sweep_bf16_1<4>), grid, block, 0, s, A);

@@ -522,10 +522,12 @@ int fic_ctx_encode(fic_ctx* c, int range_begin, int range_count, void* hip_strea
         // FIC_SWEEP=3 opts the whole process into the matrix-core sweep wherever it is built (same results);
         // other geometries keep the VALU sweep.  An explicit fic_ctx_set_option("sweep", ...) wins.
         const char* env = getenv("FIC_SWEEP");
-        // Below ~5e8 (range, domain) pairs per launch (one 512x512 image: 6.4e7) the VALU sweep is faster: the
-        // matrix-core kernels' per-chunk start-up does not amortise (measured 0.45 vs 0.70 ms), so keep it there.
+        // Small launches stay on the VALU sweep, where it is faster: the bf16-operand kernels (B = 4/8) win from about
+        // one 512x512 image (6.4e7 (range, domain) pairs: 0.19 vs 0.45 ms) upwards, the i8-operand kernels (B = 16)
+        // need ~5e8 pairs to amortise their per-chunk start-up.
         const long long pairs = (long long)g.planes * range_count * g.Nd;
-        if (env && env[0] == '3' && env[1] == '\0' && g.full && pairs >= 500000000LL) kind = 3;
+        const long long enough = g.B <= 8 ? 50000000LL : 500000000LL;
+        if (env && env[0] == '3' && env[1] == '\0' && g.full && pairs >= enough) kind = 3;
     }
     if (kind >= 2 && !g.full) return fail(FIC_E_ARGUMENT, "fast sweep needs full search (wK == Dw == Dh)");
 

@@ -158,10 +158,12 @@ FIC_API int fic_ctx_decode_host(fic_ctx* ctx, uint8_t* gray_out, float* avg_erro
 
 /* Tuning / instrumentation knobs:
  *   "sweep"       0 auto (VALU fast kernel for full search, generic otherwise), 1 generic, 2 fast,
- *                 3 = opt-in matrix-core sweep (B = 4/8/16, n_iso = 1 or 8, full search; same results)
- *                 (with "sweep" = 0 the environment variable FIC_SWEEP=3 selects it process-wide for full-search
- *                 launches of >= 5e8 (range, domain) pairs; smaller launches and windowed search keep the
- *                 VALU sweep, which is faster there)
+ *                 3 = opt-in matrix-core sweep (B = 4/8/16, n_iso = 1 or 8, full search; same results): bf16
+ *                     operands at B = 4/8 (centred pixels are exact bf16), i8 operands at B = 16
+ *                 4 = matrix-core sweep with i8 operands at every block size (the round's first kernels; kept)
+ *                 (with "sweep" = 0 the environment variable FIC_SWEEP=3 selects the matrix-core sweep process-wide
+ *                 for full-search launches of >= 5e7 (B = 4/8) / 5e8 (B = 16) (range, domain) pairs; smaller
+ *                 launches and windowed search keep the VALU sweep, which is faster there)
  *   "chunks"      domain-pool chunks per range tile for the fast kernel (0 = auto)
  *   "time_sweep"  1: bracket every sweep launch with hipEvents on its stream */
 FIC_API int fic_ctx_set_option(fic_ctx* ctx, const char* name, int value);
