@@ -287,7 +287,8 @@ def main():
                                "unit": "TFLOP/s" if bf16 else "TOP/s", "frac": ops / (avg_ms * 1e-3) / 1e12 / peak,
                                "traffic": None, "kernel": kname, "avg_launch_ms": avg_ms, "launches": sweep_n,
                                "note": "opt-in (--sweep 3/4): north_star rules MFMA out for this path; default is the VALU sweep"}
-            vpe = (20.0 / 32.0 if n_iso == 8 else 19.0 / 32.0) if bf16 else (3.5 if n_iso == 8 else 6.0)
+            # bf16 kernels: 28 (8 iso) / 27 (1 iso) VALU wave-instructions per 32x32 tile of pair evaluations (ISA count)
+            vpe = (28.0 * 64 / 1024 if n_iso == 8 else 27.0 * 64 / 1024) if bf16 else (3.5 if n_iso == 8 else 6.0)
             out["valu"] = {"bound": "valu-issue (epilogue)", "valu_instr_per_pair_eval": vpe,
                            "frac": pair_evals * vpe / 64.0 / (avg_ms * 1e-3) / VALU_WAVE_INSTR_PEAK,
                            "peak_wave_instr_per_s": VALU_WAVE_INSTR_PEAK}

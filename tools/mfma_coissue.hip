@@ -31,10 +31,8 @@ __global__ __launch_bounds__(256) void k(const v4i* in, float* out, float w, flo
     int hits = 0;
     if (MODE >= 2) { for (int m = 0; m < 4; m++) acc = mf(a[m], b[m], acc); }
     for (int it = 0; it < ITER; it++) {
-        if (MODE == 0) {
-            acc = zero;
+        if (MODE == 0) {                                   // one long dependent chain: nothing for the compiler to drop
             for (int m = 0; m < 4; m++) acc = mf(a[m], b[m], acc);
-            b[0][0] ^= it;
             continue;
         }
         if (MODE == 2 || MODE == 3) { nacc = zero; for (int m = 0; m < 4; m++) nacc = mf(a[m], b[m], nacc); }
