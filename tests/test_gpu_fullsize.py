@@ -95,3 +95,30 @@ def test_cfg4_size_reference_algorithm_and_S_image(oracle):
     for j, (idx, ab, iso, err) in ref.items():
         o = j - b
         assert fast["idx_local"][o] == idx and same_f32(np.array([fast["a"][o], fast["b"][o]]), ab)
+
+
+@pytest.mark.parametrize("size,B,n_iso,dist", [(4096, 8, 8, "U"), (4096, 8, 1, "S"), (2048, 4, 1, "U"), (2048, 4, 8, "S"),
+                                                (4096, 16, 1, "S"), (2048, 16, 8, "U")])
+def test_whole_codebook_at_full_size_valu_equals_matrix_core(size, B, n_iso, dist):
+    """Every range block of a BASELINE-sized image through two independent sweeps -- the VALU kernel (integer dot
+    products, range blocks in lanes) and the matrix-core kernel (bf16 / i8 MFMA tiles, deferred exact epilogue): the
+    whole codebook, the unquantised fit and the winning errors must be the same bits, and so must the `.run` bytes."""
+    import hashlib
+    g = (synth.image_u if dist == "U" else synth.image_s)(size, size, synth.SEEDS["cfg4"] + B + n_iso)
+    res = {}
+    with fic_amd.Encoder(size, size, B, None, n_iso) as enc:
+        enc.set_gray(g)
+        for sweep in (2, 3):
+            enc.set_option("sweep", sweep)
+            enc.encode()
+            res[sweep] = {k: v[0].copy() for k, v in enc.results().items()}
+            assert enc.info()["sweep_kind"] == sweep
+        wK = enc.wK
+    _same(res[2], res[3])
+    runs = [hashlib.sha256(fic_amd.write_run_gray(res[s]["qrows"], size, size, B, wK)).hexdigest() for s in (2, 3)]
+    assert runs[0] == runs[1]
+    # not a degenerate comparison: the codebook uses many different domain blocks (and isometries); the S images are
+    # mostly flat 32x32 tiles (rem == 0 -> index 0, FC:677), so only their noisy half spreads out
+    assert len(np.unique(res[2]["idx_local"])) > (1000 if dist == "U" else 10)
+    if n_iso == 8 and dist == "U":
+        assert len(np.unique(res[2]["iso"])) == 8
