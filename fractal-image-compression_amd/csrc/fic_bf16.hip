@@ -10,15 +10,16 @@
 // dM = Domainblock.mittelWert DB:92-98) are exact bf16 values, every product (<= 255^2) and every partial sum
 // (|.| <= n * 255^2 <= 64 * 65025 < 2^24) is an exactly representable f32 integer, and
 //     v_mfma_f32_32x32x16_bf16  accumulates  kovarianz = sum_i (r_i - rM) * (d_i - dM)     (FC:665-672)
-// itself -- exactly, in any summation order -- straight into the accumulator.  The epilogue shrinks to one
-// multiply, two max3 and one compare per 4 accumulator elements, and the kernel becomes MFMA-bound (4 x 32 cycles
-// per tile at B = 8).  At B = 16 (n = 256: 16 bf16 steps against 8 i8 steps, 256 * 255^2 still < 2^24) the i8 kernels
-// are already MFMA-bound and stay the better choice.
+// itself -- exactly, in any summation order -- straight into the accumulator.  The epilogue shrinks from 56 to 28
+// VALU instructions per 32x32 tile (16 multiplies by fl(1/s32), a max3 tree, one compare per range block).  At B = 16
+// (n = 256: 16 bf16 steps against 8 i8 steps; 256 * 255^2 would still be < 2^24) the i8 kernels stay the better choice.
 //
-// Everything after the accumulator -- the conservative f32 prune test with its 2^-18 margin, the exact f64 epilogue,
-// the (error, candidate) lexicographic 64-bit atomicMin, tau raised by the exact path, the forced first tile of
-// every pool chunk -- is the arithmetic of k_sweep_fast / k_sweep_mfma, so the result is the
-// same bits; tests/test_gpu_mfma.py compares all sweeps against the oracle.
+// What is the same as in k_sweep_fast / k_sweep_mfma, so that the result is the same bits: a
+// conservative f32 prune test with a 2^-18 margin, the exact f64 Java epilogue for every pair that fails it, the
+// (error, candidate) lexicographic 64-bit atomicMin, tau only ever raised by pairs of lower index that ARE evaluated,
+// the exactly evaluated first tile of every pool chunk.  What differs is when the exact epilogue runs (deferred, from
+// an LDS queue) and the level tau is raised with (the tested product times (1 - 2^-17), below).
+// tests/test_gpu_mfma.py and tests/test_gpu_fullsize.py compare all sweeps against the oracle and each other.
 //
 // Fragment format (both operands; A rows and B columns use the same lane map, cdna_hip_programming.md section 3):
 //   frag[tile][m][lane] = 8 bf16 = pixels [16m + 8h, 16m + 8h + 8) of row/column (lane & 31), h = lane >> 5,
@@ -33,7 +34,6 @@
 
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef float v16f __attribute__((ext_vector_type(16)));
-typedef float v2f __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 // Level of a pair as the sweeps raise tau with it: the tested product |cov| * fl(1/s32) times (1 - 2^-17).  It is below
 // the pair's true |cov| / sqrt(var) by at least 2^-18 relative (the product carries < 2^-22 of rounding), so a later
