@@ -121,14 +121,14 @@ int dev_alloc(T** p, size_t count)
 
 int ctx_free_all(fic_ctx* c)
 {
-    hipSetDevice(c->device);
-    for (hipEvent_t e : c->ev) hipEventDestroy(e);
+    (void)hipSetDevice(c->device);
+    for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
     c->ev.clear();
     void* ptrs[] = {c->gray_own, c->argb_stage, c->collage, c->decoded, c->mfma_poolB, c->mfma_rngA, c->mfma_sw, c->mfma_rconst, c->b.scaled, c->b.pool_pix, c->b.pool_st, c->b.pool_var,
                     c->b.pool_s64, c->b.rng_pix, c->b.rng_st, c->b.key, c->o.idx_local, c->o.idx_global, c->o.iso,
                     c->o.a, c->o.b, c->o.err, c->o.qrows};
     for (void* p : ptrs)
-        if (p) hipFree(p);
+        if (p) (void)hipFree(p);
     return FIC_OK;
 }
 
@@ -140,8 +140,8 @@ int flush_events(fic_ctx* c)
         HIP_TRY(hipEventElapsedTime(&ms, c->ev[i], c->ev[i + 1]));
         c->acc_ms += ms;
         c->acc_n += 1;
-        hipEventDestroy(c->ev[i]);
-        hipEventDestroy(c->ev[i + 1]);
+        (void)hipEventDestroy(c->ev[i]);
+        (void)hipEventDestroy(c->ev[i + 1]);
     }
     c->ev.clear();
     return FIC_OK;
@@ -451,8 +451,8 @@ fic_ctx* fic_ctx_create(int device, int w, int h, int B, int wK, int n_iso, int 
 void fic_ctx_destroy(fic_ctx* c)
 {
     if (!c) return;
-    hipSetDevice(c->device);
-    hipDeviceSynchronize();
+    (void)hipSetDevice(c->device);
+    (void)hipDeviceSynchronize();
     ctx_free_all(c);
     delete c;
 }
@@ -668,7 +668,7 @@ int fic_debug_sqrt_f64(int device, uint32_t first, uint32_t count, double* out)
         hipError_t e = hipMemcpy(out, d, (size_t)count * sizeof(double), hipMemcpyDeviceToHost);
         if (e != hipSuccess) rc = fail(FIC_E_HIP, "hipMemcpy: %s", hipGetErrorString(e));
     }
-    hipFree(d);
+    (void)hipFree(d);
     return rc;
 }
 
@@ -728,7 +728,7 @@ static int run_decode_loop(const FicGeom& g, uint8_t* d_scaled, uint8_t* d_image
             if (all) break;
         }
     }
-    hipFree(d_state);
+    (void)hipFree(d_state);
     if (rc != FIC_OK) return rc;
     for (size_t p = 0; p < P; p++) {
         if (st[p].bad_index)
@@ -795,7 +795,7 @@ int fic_decode_gray_run(const uint8_t* run, int64_t len, int device, uint8_t* gr
         if (e != hipSuccess) rc = fail(FIC_E_HIP, "fic_decode_gray_run: %s", hipGetErrorString(e));
     }
     if (rc == FIC_OK && avg_error_io) *avg_error_io = avg;
-    hipFree(d_scaled); hipFree(d_image); hipFree(d_q);
+    (void)hipFree(d_scaled); (void)hipFree(d_image); (void)hipFree(d_q);
     return rc;
 }
 
@@ -860,7 +860,7 @@ int fic_decode_rgb_run(const uint8_t* run, int64_t len, int device, int32_t* arg
         if (avg_error_io) *avg_error_io = st.avg_out;
         if (iterations) *iterations = st.iters;
     }
-    hipFree(d_scaled); hipFree(d_image); hipFree(d_q); hipFree(d_state);
+    (void)hipFree(d_scaled); (void)hipFree(d_image); (void)hipFree(d_q); (void)hipFree(d_state);
     return rc;
 }
 
@@ -917,7 +917,7 @@ int fic_encode_rgb_argb(const int32_t* argb, int w, int h, int B, int wK, int de
     void* ptrs[] = {b.argb, b.scaled, b.pool_sum, b.pool_st, b.rng_t, b.rng_st, b.key, o.idx_local, o.idx_global,
                     o.a, o.bR, o.bG, o.bB, o.qrows, d_collage};
     for (void* p : ptrs)
-        if (p) hipFree(p);
+        if (p) (void)hipFree(p);
     return rc;
 }
 
