@@ -3,17 +3,27 @@
 //   host_mirror_test encode      <gray.raw u8>   w h B wK out.run collage.raw
 //   host_mirror_test encode_argb <argb.raw i32>  w h B wK out.run collage.raw     (colour -> encodeRGB)
 //   host_mirror_test decode      <in.run> out_argb.raw                            (prints avgError)
+//   host_mirror_test synth       U|S w h seed out.raw                             (include/fic_synth.h; no GPU needed)
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
 #include <iostream>
 #include "fic_host.hpp"
+#include "fic_synth.h"
 
 using FC = bvk_ss19::FractalCompression;
 
 static int run(int argc, char** argv)
 {
+    if (argc == 7 && !std::strcmp(argv[1], "synth")) {
+        const int w = std::atoi(argv[3]), h = std::atoi(argv[4]);
+        std::vector<uint8_t> img((size_t)w * h);
+        fic_synth_image(argv[2][0], w, h, std::strtoull(argv[5], nullptr, 0), img.data());
+        std::ofstream o(argv[6], std::ios::binary);
+        o.write(reinterpret_cast<const char*>(img.data()), (std::streamsize)img.size());
+        return 0;
+    }
     if (argc >= 4 && !std::strcmp(argv[1], "decode")) {
         std::ifstream in(argv[2], std::ios::binary);
         bvk_ss19::RasterImage img = FC::decode(in);

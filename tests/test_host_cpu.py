@@ -150,3 +150,18 @@ def test_pack_unpack_records_roundtrip():
         assert (back[k] == res[k][:, 10:60]).all()
     assert (back["a"].view(np.uint32) == res["a"][:, 10:60].view(np.uint32)).all()
     assert (back["b"].view(np.uint32) == res["b"][:, 10:60].view(np.uint32)).all()
+
+
+@pytest.mark.parametrize("kind", ["U", "S"])
+@pytest.mark.parametrize("w,h,seed", [(64, 64, 0xF1C0002), (200, 96, 11), (512, 512, 0xF1C0004), (96, 160, 0xF1C0005 + 3 * 7 + 2)])
+def test_synthetic_inputs_are_the_same_bytes_in_c_and_python(tmp_path, kind, w, h, seed):
+    """the benchmark inputs must be generated identically in C/C++ and Python (no RNG library).
+    include/fic_synth.h (through the C++ driver) against fractal-image-compression_amd/synth.py."""
+    import os
+    drv = os.path.join(os.path.dirname(__file__), "cpp", "host_mirror_test")
+    if not os.path.exists(drv):
+        pytest.skip("C++ driver not built (run __graft_entry__.build())")
+    out = tmp_path / "img.raw"
+    subprocess.check_call([drv, "synth", kind, str(w), str(h), hex(seed), str(out)])
+    got = np.fromfile(out, np.uint8).reshape(h, w)
+    assert (got == fic_amd.synth.image(kind, w, h, seed)).all()
