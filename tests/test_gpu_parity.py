@@ -481,9 +481,7 @@ def test_seeded_fuzz_geometries_windows_sweeps(oracle):
         ref = oracle.encode_gray(oracle.gray_to_argb(g), w, h, B, wK, n_iso)
         sweeps = [1]
         if wK == Dw == Dh:
-            sweeps.append(2)
-            if n_iso == 1 or B == 8:
-                sweeps.append(3)
+            sweeps += [2, 3, 4]                         # VALU, matrix-core (bf16 / i8 by block size), matrix-core i8
         for sweep in sweeps:
             got = fic_amd.encode_gray(g, B, wK, n_iso, sweep=sweep, chunks=int(rng.integers(0, 4)) if sweep >= 2 else 0)
             try:
