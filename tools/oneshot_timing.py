@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""PCIe-inclusive rates of the one-shot C entry point (host buffers in, host results out, context
-created per call) and a full-size encode -> decode round trip.  Never bench.py's `value`."""
+"""PCIe-inclusive rates of the one-shot C entry point (host buffers in, host results out; the working set of a
+geometry is cached between calls, `ms_per_call_cold` is the first call after fic_release_cache; run with FIC_SWEEP=3
+in the environment for the matrix-core sweeps) and a full-size encode -> decode round trip.  Never bench.py's `value`."""
 import json
 import os
 import sys
@@ -22,8 +23,10 @@ for name, (W, B, n_iso) in {"cfg2_single_8iso": (512, 8, 8), "cfg2_single_1iso":
     t0 = time.perf_counter()
     capi.encode_gray_oneshot(g, B, None, n_iso)                 # cold: allocates the working set
     cold = time.perf_counter() - t0
+    for _ in range(2):
+        capi.encode_gray_oneshot(g, B, None, n_iso)             # first uses of a fresh working set still fault pages in
     t0 = time.perf_counter()
-    reps = 5
+    reps = 10
     for _ in range(reps):
         r = capi.encode_gray_oneshot(g, B, None, n_iso)         # warm: working set reused from the cache
     dt = (time.perf_counter() - t0) / reps
