@@ -108,7 +108,7 @@ def main():
     ap.add_argument("--chunks", type=int, default=0)
     ap.add_argument("--sweep", type=int, default=0, choices=[0, 2, 3, 4],
                     help="0/2 = VALU sweep k_sweep_fast (default, north_star's design); 3 = opt-in matrix-core sweep "
-                         "(bf16 operands at B = 4/8, i8 at B = 16); 4 = matrix-core sweep with i8 operands at every B")
+                         "(bf16 operands; i8 at B = 16 with 1 isometry); 4 = matrix-core sweep with i8 operands at every B")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-alt", action="store_true", help="skip the extra timing of the opt-in matrix-core sweep")
     ap.add_argument("--cpu-budget", type=float, default=12.0)
@@ -272,10 +272,10 @@ def main():
                              "SQ_ACTIVE_INST_VALU = 96% of kernel cycles (profiles/r01a_cfg2_pmc_summary.txt)"},
         }
         if info["sweep_kind"] >= 3:
-            # opt-in matrix-core sweeps.  B = 4/8 with "sweep" = 3: centred pixels as exact bf16 operands of
+            # opt-in matrix-core sweeps.  "sweep" = 3 at B = 4/8 (and B = 16 with 8 isometries): centred pixels as exact bf16 operands of
             # v_mfma_f32_32x32x16_bf16 (dense bf16 peak 2.5 PFLOP/s); otherwise u8 shifted to i8 on
             # v_mfma_i32_32x32x32_i8 (dense i8 peak 5.0 PetaOP/s) -- MI355X_MICROARCH.md "Matrix cores".
-            bf16 = info["sweep_kind"] == 3 and B <= 8
+            bf16 = info["sweep_kind"] == 3 and (B <= 8 or n_iso == 8)
             kname = ("k_sweep_bf16" if bf16 else "k_sweep_mfma") + ("" if n_iso == 8 else ("_1" if bf16 else "1"))
             peak = 2500.0 if bf16 else 5000.0
             ops = pair_evals * 2.0 * n
@@ -308,12 +308,11 @@ def main():
             core.set_option("sweep", 0)
             out["opt_in_matrix_core"] = {
                 "how": "bench.py --sweep 3 / fic_ctx_set_option(ctx, \"sweep\", 3)",
-                "kernel": (("k_sweep_bf16" if n_iso == 8 else "k_sweep_bf16_1") if B <= 8 else
-                           ("k_sweep_mfma" if n_iso == 8 else "k_sweep_mfma1")),
+                "kernel": (("k_sweep_bf16" if n_iso == 8 else "k_sweep_bf16_1") if (B <= 8 or n_iso == 8) else "k_sweep_mfma1"),
                 "value": total_ranges / dt3, "unit": "range-block matches/s", "ms_per_step": dt3 / args.steps * 1e3,
                 "avg_launch_ms": ms3 / max(n3, 1), "speedup_vs_default": dt / dt3,
                 "note": "bit-identical codebooks (tests/test_gpu_mfma.py); inner products on v_mfma_f32_32x32x16_bf16 "
-                        "(B = 4/8: centred pixels are exact bf16) or v_mfma_i32_32x32x32_i8 (B = 16). "
+                        "(centred pixels are exact bf16) or, at B = 16 with 1 isometry, v_mfma_i32_32x32x32_i8. "
                         "Not the default because north_star asks for a VALU-only sweep (DESIGN.md section 6)."}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(wl, imgs[0], args.cpu_budget)

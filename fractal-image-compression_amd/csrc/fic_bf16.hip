@@ -1,4 +1,4 @@
-// fic_bf16.hip -- OPT-IN matrix-core sweeps with bf16 operands ("sweep" = 3 at B = 4 and B = 8): k_sweep_bf16<NK>
+// fic_bf16.hip -- OPT-IN matrix-core sweeps with bf16 operands ("sweep" = 3 at B = 4, B = 8, and B = 16 with 8 isometries): k_sweep_bf16<NK>
 // (8 isometries) and k_sweep_bf16_1<NK> (reference algorithm, 1 isometry).  gfx950 (MI355X / CDNA4) only, wave64.
 // Compile with -ffp-contract=off (every float expression rounds once per operation, like the Java reference:
 // FractalCompression.java = FC, Domainblock.java = DB).
@@ -12,7 +12,9 @@
 //     v_mfma_f32_32x32x16_bf16  accumulates  kovarianz = sum_i (r_i - rM) * (d_i - dM)     (FC:665-672)
 // itself -- exactly, in any summation order -- straight into the accumulator.  The epilogue shrinks from 56 to 28
 // VALU instructions per 32x32 tile (16 multiplies by fl(1/s32), a max3 tree, one compare per range block).  At B = 16
-// (n = 256: 16 bf16 steps against 8 i8 steps; 256 * 255^2 would still be < 2^24) the i8 kernels stay the better choice.
+// (n = 256: 16 bf16 steps against 8 i8 steps; 256 * 255^2 = 16 646 400 is still < 2^24) the 8-isometry kernel is
+// faster than its i8 counterpart (51 vs 79 ms at 4096x4096), the 1-isometry kernel is not (9.2 vs 8.6 ms) and the i8
+// kernel k_sweep_mfma1 stays in use there.
 //
 // What is the same as in k_sweep_fast / k_sweep_mfma, so that the result is the same bits: a
 // conservative f32 prune test with a 2^-18 margin, the exact f64 Java epilogue for every pair that fails it, the
@@ -175,15 +177,16 @@ struct Bf16Args {
     int group0, ngroups_launch;      // first workgroup-sized range group of this shard, groups in this launch
     int tiles_per_chunk, nchunks, planes;
 };
-#define FIC_BF16_T 4                 // row tiles per wave
-#define FIC_BF16_RT 16               // row tiles per workgroup (64 range blocks)
+// Row (column) tiles per wave: 4 at B = 4/8 (a workgroup = 64 range blocks x 8 copies, or 512 range blocks); 2 at
+// B = 16, where one tile's fragments already take 64 VGPRs (the kernel then runs one wave per SIMD).
+__host__ __device__ constexpr int fic_bf16_T(int NK) { return NK <= 4 ? 4 : 2; }
 #define FIC_BF16_QCAP 1280           // queue entries per wave: one tile can flag at most 1024 pairs
 #define FIC_BF16_QFLUSH 256          // evaluate the queue before a tile's pushes once it holds this many
 
 template <int NK>
 __global__ __launch_bounds__(256) void k_sweep_bf16(Bf16Args A)
 {
-    constexpr int T = FIC_BF16_T, RT = FIC_BF16_RT;
+    constexpr int T = fic_bf16_T(NK), RT = 4 * T;
     __shared__ uint2 sQ[4][FIC_BF16_QCAP];             // per wave: {covariance (f32 bits), candidate | range-in-wave << 27}
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -384,13 +387,11 @@ struct Bf16Args1 {
     int nctg;                        // column-tile groups (workgroups) in this launch
     int tiles_per_chunk, nchunks, planes;
 };
-#define FIC_BF16_CTW 4
-#define FIC_BF16_CT 16
 
 template <int NK>
 __global__ __launch_bounds__(256) void k_sweep_bf16_1(Bf16Args1 A)
 {
-    constexpr int CTW = FIC_BF16_CTW, CT = FIC_BF16_CT;
+    constexpr int CTW = fic_bf16_T(NK), CT = 4 * CTW;
     __shared__ uint32_t sTau[CT * 32];
     __shared__ uint2 sQ[4][FIC_BF16_QCAP];             // per wave: {covariance (f32 bits), domain block | range-in-wave << 24}
     const int lane = threadIdx.x & 63;
@@ -563,8 +564,8 @@ __global__ __launch_bounds__(256) void k_sweep_bf16_1(Bf16Args1 A)
 // host-side launchers
 // ---------------------------------------------------------------------------------------------
 int fic_bf16_steps(int B) { return B * B / 16; }
-int fic_bf16_group8(void) { return FIC_BF16_RT * 4; }        // range blocks per workgroup, 8-isometry kernel
-int fic_bf16_ct1(void) { return FIC_BF16_CT; }               // column tiles (x32 ranges) per workgroup, 1-isometry kernel
+int fic_bf16_group8(int B) { return 16 * fic_bf16_T(B * B / 16); }   // range blocks per workgroup, 8-isometry kernel
+int fic_bf16_ct1(int B) { return 4 * fic_bf16_T(B * B / 16); }       // column tiles (x32 ranges) per workgroup, 1-isometry kernel
 
 int fic_launch_bf16_prep(const FicBuffers& b, void* poolF, void* pool_w, void* rngF, const FicGeom& g, int ndtiles_alloc,
                          int nrtiles_alloc, hipStream_t s)
@@ -593,10 +594,11 @@ int fic_launch_sweep_bf16(const FicBuffers& b, const void* poolF, const void* po
     A.ndtiles = ndtiles; A.ndtiles_alloc = ndtiles_alloc; A.nrtiles_alloc = nrtiles_alloc;
     A.group0 = group0; A.ngroups_launch = ngroups_launch; A.tiles_per_chunk = tiles_per_chunk; A.nchunks = nchunks;
     A.planes = g.planes;
-    if ((group0 + ngroups_launch) * FIC_BF16_RT > nrtiles_alloc || g.Nd >= (1 << 24)) return (int)hipErrorInvalidValue;
+    if ((group0 + ngroups_launch) * (fic_bf16_group8(g.B) / 4) > nrtiles_alloc || g.Nd >= (1 << 24)) return (int)hipErrorInvalidValue;
     dim3 grid((unsigned)(nchunks * g.planes) * (unsigned)ngroups_launch), block(256);
     if (g.B == 4) hipLaunchKernelGGL((k_sweep_bf16<1>), grid, block, 0, s, A);
     else if (g.B == 8) hipLaunchKernelGGL((k_sweep_bf16<4>), grid, block, 0, s, A);
+    else if (g.B == 16) hipLaunchKernelGGL((k_sweep_bf16<16>), grid, block, 0, s, A);
     else return (int)hipErrorInvalidValue;
     FIC_LAUNCH_CHECK();
     return 0;
@@ -612,12 +614,14 @@ int fic_launch_sweep_bf16_1(const FicBuffers& b, const void* poolF, const void* 
     A.Nd = g.Nd; A.Nd_pad = g.Nd_pad; A.Nr = g.Nr; A.Nr_pad = g.Nr_pad;
     A.ndtiles = ndtiles; A.ndtiles_alloc = ndtiles_alloc; A.nctiles_alloc = nctiles_alloc;
     A.ct_begin = ct_begin; A.ct_end = ct_end; A.tiles_per_chunk = tiles_per_chunk; A.nchunks = nchunks;
-    A.nctg = (ct_end - ct_begin + FIC_BF16_CT - 1) / FIC_BF16_CT;
+    const int CT = fic_bf16_ct1(g.B);
+    A.nctg = (ct_end - ct_begin + CT - 1) / CT;
     A.planes = g.planes;
-    if (ct_begin + A.nctg * FIC_BF16_CT > nctiles_alloc || g.Nd >= (1 << 24)) return (int)hipErrorInvalidValue;
+    if (ct_begin + A.nctg * CT > nctiles_alloc || g.Nd >= (1 << 24)) return (int)hipErrorInvalidValue;
     dim3 grid((unsigned)(nchunks * g.planes) * (unsigned)A.nctg), block(256);
     if (g.B == 4) hipLaunchKernelGGL((k_sweep_bf16_1<1>), grid, block, 0, s, A);
     else if (g.B == 8) hipLaunchKernelGGL((k_sweep_bf16_1<4>), grid, block, 0, s, A);
+    else if (g.B == 16) hipLaunchKernelGGL((k_sweep_bf16_1<16>), grid, block, 0, s, A);
     else return (int)hipErrorInvalidValue;
     FIC_LAUNCH_CHECK();
     return 0;

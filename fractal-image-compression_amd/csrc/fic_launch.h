@@ -88,8 +88,8 @@ int fic_launch_sweep_mfma1(const FicBuffers& b, const void* poolA, const void* p
                            int nctiles_alloc, int tiles_per_chunk, int nchunks, hipStream_t s);
 // bf16-operand matrix-core sweeps (fic_bf16.hip): "sweep" = 3 at B = 4 / 8
 int fic_bf16_steps(int B);           // MFMA steps of K = 16 per block
-int fic_bf16_group8(void);           // range blocks per workgroup, 8-isometry kernel
-int fic_bf16_ct1(void);              // column tiles (x32 ranges) per workgroup, 1-isometry kernel
+int fic_bf16_group8(int B);          // range blocks per workgroup, 8-isometry kernel
+int fic_bf16_ct1(int B);             // column tiles (x32 ranges) per workgroup, 1-isometry kernel
 int fic_launch_bf16_prep(const FicBuffers& b, void* poolF, void* pool_w, void* rngF, const FicGeom& g, int ndtiles_alloc,
                          int nrtiles_alloc, hipStream_t s);
 int fic_launch_sweep_bf16(const FicBuffers& b, const void* poolF, const void* pool_w, const void* rngF, const FicGeom& g,

@@ -159,7 +159,8 @@ FIC_API int fic_ctx_decode_host(fic_ctx* ctx, uint8_t* gray_out, float* avg_erro
 /* Tuning / instrumentation knobs:
  *   "sweep"       0 auto (VALU fast kernel for full search, generic otherwise), 1 generic, 2 fast,
  *                 3 = opt-in matrix-core sweep (B = 4/8/16, n_iso = 1 or 8, full search; same results): bf16
- *                     operands at B = 4/8 (centred pixels are exact bf16), i8 operands at B = 16
+ *                     operands (centred pixels are exact bf16) at B = 4/8 and at B = 16 with 8 isometries, i8
+ *                     operands at B = 16 with 1 isometry -- whichever is faster
  *                 4 = matrix-core sweep with i8 operands at every block size (the round's first kernels; kept)
  *                 (with "sweep" = 0 the environment variable FIC_SWEEP=3 selects the matrix-core sweep process-wide
  *                 for full-search launches of >= 5e7 (B = 4/8) / 5e8 (B = 16) (range, domain) pairs; smaller
