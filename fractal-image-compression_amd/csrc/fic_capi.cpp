@@ -888,6 +888,7 @@ int fic_encode_rgb_argb(const int32_t* argb, int w, int h, int B, int wK, int de
     M((void**)&b.argb, npix * 4);
     M((void**)&b.scaled, (size_t)g.Ws * g.Hs * 4);
     M((void**)&b.pool_sum, nd * n * 2);
+    if (g.full && g.B <= 8) M((void**)&b.pool_cf, nd * n * 4);      // fast full-search sweep (k_sweep_rgb_fast)
     M((void**)&b.pool_st, nd * sizeof(FicRgbDomStat));
     M((void**)&b.rng_t, nr * n * 2);
     M((void**)&b.rng_st, nr * sizeof(FicRgbRngStat));
@@ -916,7 +917,7 @@ int fic_encode_rgb_argb(const int32_t* argb, int w, int h, int B, int wK, int de
     D(bB, o.bB, nr * 4);
     D(qrows5, o.qrows, nr * 20);
     D(collage_argb, d_collage, npix * 4);
-    void* ptrs[] = {b.argb, b.scaled, b.pool_sum, b.pool_st, b.rng_t, b.rng_st, b.key, o.idx_local, o.idx_global,
+    void* ptrs[] = {b.argb, b.scaled, b.pool_sum, b.pool_cf, b.pool_st, b.rng_t, b.rng_st, b.key, o.idx_local, o.idx_global,
                     o.a, o.bR, o.bG, o.bB, o.qrows, d_collage};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);

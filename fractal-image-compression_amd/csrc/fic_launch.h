@@ -64,6 +64,7 @@ struct FicRgbBuffers {
     int32_t* argb;           // input [H][W]
     int32_t* scaled;         // [H/2][W/2] packed ARGB
     uint16_t* pool_sum;      // [N_d][n]  R+G+B per domain pixel
+    float* pool_cf;          // [N_d][n]  greyD_i = pool_sum - msum as exact f32 (full search at B = 4 / 8 only, else NULL)
     FicRgbDomStat* pool_st;  // [N_d]
     int16_t* rng_t;          // [N_r][n]  greyR_i
     FicRgbRngStat* rng_st;   // [N_r]

@@ -137,6 +137,61 @@ __global__ __launch_bounds__(256) void k_sweep_rgb(const uint16_t* __restrict__ 
     if (lane == 0) key[j] = best;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Full search (wK == Dw == Dh), B = 4 / 8: the k_sweep_fast mapping for the joint-RGB error.
+// k_sweep_rgb gives every lane its own candidate, so a wave-level load touches 64 different pool blocks (2-byte
+// reads, 128-byte stride): fine for the GUI's small windows, 8.8e9 pairs/s on a full pool.  Here lane = range block
+// (its n greyR_i sit in VGPRs as exact f32 integers) and the domain block is wave-uniform: greyD_i = (R+G+B)_i - msum
+// comes from a pre-centred f32 copy of the pool through the scalar cache and feeds v_mul_f32 as an SGPR operand.
+// The arithmetic per pair is the reference's, in the reference's order: kov += greyR_i * greyD_i for i = 0..n-1
+// (exact product < 2^24, one f32 rounding per add, FC:781-792), then FC:794-803.  Pool chunks run in different
+// workgroups and meet in the (error, candidate) key through a 64-bit atomicMin, as in the grey sweeps.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_pool_rgb_centred(const uint16_t* __restrict__ pool_sum, const FicRgbDomStat* __restrict__ st,
+                                                          float* __restrict__ pool_cf, FicGeom g)
+{
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)g.Nd * g.n) return;
+    pool_cf[i] = (float)((int)pool_sum[i] - st[i >> g.lgn].msum);           // greyD_i, |.| <= 765: exact
+}
+
+template <int N>
+__global__ __launch_bounds__(256) void k_sweep_rgb_fast(const float* __restrict__ pool_cf, const FicRgbDomStat* __restrict__ dst,
+                                                        const int16_t* __restrict__ rng_t, const FicRgbRngStat* __restrict__ rst,
+                                                        unsigned long long* __restrict__ key, FicGeom g, int chunk_len)
+{
+    const int lane = threadIdx.x & 63;
+    const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);                  // 64 range blocks per wave
+    if (tile * 64 >= g.Nr) return;
+    const int j = tile * 64 + lane;
+    const int jj = j < g.Nr ? j : g.Nr - 1;                                // tail lanes shadow the last block
+    const int d0 = blockIdx.y * chunk_len;
+    int d1 = d0 + chunk_len;
+    if (d1 > g.Nd) d1 = g.Nd;
+    float rt[N];
+#pragma unroll
+    for (int i = 0; i < N; i++) rt[i] = (float)rng_t[(size_t)jj * N + i];  // greyR_i, |.| <= 765: exact
+    const FicRgbRngStat rs = rst[jj];
+    const float vRf = (float)rs.vR;
+    const float vR2 = __fmul_rn(vRf, vRf);
+    const AS4 float* pc = (const AS4 float*)pool_cf;
+    const AS4 FicRgbDomStat* ds4 = (const AS4 FicRgbDomStat*)dst;
+    unsigned long long best = FIC_KEY_NONE;
+    for (int d = d0; d < d1; d++) {
+        const AS4 float* gd = pc + (size_t)d * N;
+        float kov = 0.0f;
+#pragma unroll
+        for (int i = 0; i < N; i++) kov = __fadd_rn(kov, __fmul_rn(rt[i], gd[i]));
+        const int vD = ds4[d].vD;
+        float r = (rs.vR == 0 || vD == 0) ? 0.0f : __fdiv_rn(kov, __fmul_rn(vRf, (float)vD));   // FC:795-800
+        r = __fmul_rn(r, r);
+        const float e = __fmul_rn(vR2, __fsub_rn(1.0f, r));                                      // FC:801-802
+        const unsigned long long kk = ((unsigned long long)f32_orderable(e) << 32) | (uint32_t)d;
+        best = kk < best ? kk : best;
+    }
+    if (j < g.Nr && best != FIC_KEY_NONE) atomicMin(&key[j], best);
+}
+
 // getBestDomainblockRGB tail FC:717-734 + writeData RGB quantiser FC:250-254
 __global__ __launch_bounds__(256) void k_finalize_rgb(const uint16_t* __restrict__ pool_sum,
                                                       const FicRgbDomStat* __restrict__ dst,
@@ -252,8 +307,30 @@ int fic_launch_rgb_encode(const FicRgbBuffers& b, const FicRgbOutputs& out, int3
     FIC_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_range_rgb, dim3((g.Nr + 255) / 256), dim3(256), 0, s, (const int32_t*)b.argb, b.rng_t, b.rng_st, g);
     FIC_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_sweep_rgb, dim3((g.Nr + 3) / 4), dim3(256), 0, s, (const uint16_t*)b.pool_sum,
-                       (const FicRgbDomStat*)b.pool_st, (const int16_t*)b.rng_t, (const FicRgbRngStat*)b.rng_st, b.key, g);
+    if (g.full && g.B <= 8 && b.pool_cf) {
+        // full search: lane = range block, wave-uniform domain blocks, pool chunks across workgroups
+        const size_t total = (size_t)g.Nd * g.n;
+        hipLaunchKernelGGL(k_pool_rgb_centred, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s,
+                           (const uint16_t*)b.pool_sum, (const FicRgbDomStat*)b.pool_st, b.pool_cf, g);
+        FIC_LAUNCH_CHECK();
+        if (hipMemsetAsync(b.key, 0xFF, (size_t)g.Nr * sizeof(unsigned long long), s) != hipSuccess) return (int)hipErrorUnknown;
+        const int tiles = (g.Nr + 63) / 64;
+        int nchunks = (8192 + tiles - 1) / tiles;                          // ~8 waves per SIMD
+        if (nchunks > g.Nd / 64) nchunks = g.Nd / 64;
+        if (nchunks < 1) nchunks = 1;
+        const int chunk_len = (g.Nd + nchunks - 1) / nchunks;
+        nchunks = (g.Nd + chunk_len - 1) / chunk_len;
+        dim3 grid((tiles + 3) / 4, nchunks);
+        if (g.B == 4)
+            hipLaunchKernelGGL((k_sweep_rgb_fast<16>), grid, dim3(256), 0, s, (const float*)b.pool_cf, (const FicRgbDomStat*)b.pool_st,
+                               (const int16_t*)b.rng_t, (const FicRgbRngStat*)b.rng_st, b.key, g, chunk_len);
+        else
+            hipLaunchKernelGGL((k_sweep_rgb_fast<64>), grid, dim3(256), 0, s, (const float*)b.pool_cf, (const FicRgbDomStat*)b.pool_st,
+                               (const int16_t*)b.rng_t, (const FicRgbRngStat*)b.rng_st, b.key, g, chunk_len);
+    } else {
+        hipLaunchKernelGGL(k_sweep_rgb, dim3((g.Nr + 3) / 4), dim3(256), 0, s, (const uint16_t*)b.pool_sum,
+                           (const FicRgbDomStat*)b.pool_st, (const int16_t*)b.rng_t, (const FicRgbRngStat*)b.rng_st, b.key, g);
+    }
     FIC_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_finalize_rgb, dim3((g.Nr + 255) / 256), dim3(256), 0, s, (const uint16_t*)b.pool_sum,
                        (const FicRgbDomStat*)b.pool_st, (const int16_t*)b.rng_t, (const FicRgbRngStat*)b.rng_st,

@@ -67,6 +67,14 @@ def test_synthetic_colour_images(oracle, B, wK, flat):
     _check(oracle, _rgb_synth(128, 128, 77, flat), B, wK)
 
 
+@pytest.mark.parametrize("size,B,flat", [(200, 8, False), (200, 8, True), (200, 4, True), (256, 4, False), (256, 8, True)])
+def test_full_search_fast_sweep(oracle, size, B, flat):
+    """Full search at B = 4 / 8 runs k_sweep_rgb_fast (lane = range block, pool chunks across workgroups): N_r not a
+    multiple of 64 (200x200: 625 / 2500 range blocks), several pool chunks, flat blocks and ties on the S planes."""
+    Dw = fic_amd.geometry(size, size, B)[2]
+    _check(oracle, _rgb_synth(size, size, 31 + B, flat), B, Dw)
+
+
 def test_non_square_and_extremes(oracle):
     _check(oracle, _rgb_synth(192, 128, 5, True), 8, 5)          # W > H: the FC:940 height quirk
     _check(oracle, _rgb_synth(128, 192, 6), 8, 3)
