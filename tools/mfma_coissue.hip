@@ -69,6 +69,9 @@ __device__ __forceinline__ bool epilogue(const v16f& acc, float w, float tau)
 // MODE 5: no software pipelining: chain -> epilogue on the same accumulator (occupancy does the overlap).
 // MODE 6: phases of 4 tiles: 16 MFMAs into 4 accumulator sets, then the 4 epilogues.
 // MODE 7: like 2, but the accumulator is first copied to plain VGPRs with 16 v_mov (the epilogue never reads MFMA results).
+// MODE 8: three accumulator sets: the epilogue reads the set whose chain finished TWO chains ago.
+// MODE 9: like 2, but the 16 multiplies of the epilogue are issued right after the chain that produced them (before
+//         the next chain is issued), the max tree and compares beside the next chain.
 template <int MODE>
 __global__ __launch_bounds__(256) void k2(const v4i* in, float* out, float w, float tau)
 {
@@ -91,6 +94,36 @@ __global__ __launch_bounds__(256) void k2(const v4i* in, float* out, float w, fl
             for (int t = 0; t < 4; t++) if (__builtin_amdgcn_ballot_w64(epilogue(acc[t], w, tau)) != 0) { hits++; s += acc[t][3]; }
             b[0][0] ^= it;
         }
+    } else if (MODE == 8) {
+        v16f a0 = zero, a1 = zero;
+        for (int m = 0; m < 4; m++) a0 = mf(a[m], b[m], a0);
+        for (int m = 0; m < 4; m++) a1 = mf(a[m], b[(m + 1) & 3], a1);
+        for (int it = 0; it < ITER; it++) {
+            v16f a2 = zero;
+            for (int m = 0; m < 4; m++) a2 = mf(a[m], b[m], a2);
+            if (__builtin_amdgcn_ballot_w64(epilogue(a0, w, tau)) != 0) { hits++; s += a0[3]; }
+            a0 = a1; a1 = a2;
+            b[0][0] ^= it;
+        }
+        s += a0[0] + a1[0];
+    } else if (MODE == 9) {
+        v16f acc = zero;
+        for (int m = 0; m < 4; m++) acc = mf(a[m], b[m], acc);
+        float p[16];
+        for (int e = 0; e < 16; e++) p[e] = acc[e] * w;
+        for (int it = 0; it < ITER; it++) {
+            v16f nacc = zero;
+            for (int m = 0; m < 4; m++) nacc = mf(a[m], b[m], nacc);
+            bool any = false;
+            for (int q = 0; q < 4; q++) {
+                float mx = fmaxf(fmaxf(fabsf(p[4 * q]), fabsf(p[4 * q + 1])), fmaxf(fabsf(p[4 * q + 2]), fabsf(p[4 * q + 3])));
+                any |= mx > tau;
+            }
+            if (__builtin_amdgcn_ballot_w64(any) != 0) { hits++; s += p[3]; }
+            for (int e = 0; e < 16; e++) p[e] = nacc[e] * w;     // waits for the chain, then 16 multiplies with no MFMA in flight
+            b[0][0] ^= it;
+        }
+        s += p[0];
     } else {
         v16f acc = zero;
         for (int m = 0; m < 4; m++) acc = mf(a[m], b[m], acc);
@@ -142,6 +175,8 @@ int main()
         run2<5>("5 chain -> epilogue on the same accumulator, no pipelining", wps, in, out);
         run2<6>("6 phases of 4 tiles: 16 MFMAs, then 4 epilogues", wps, in, out);
         run2<7>("7 like 2, accumulator copied to plain VGPRs first", wps, in, out);
+        run2<8>("8 three accumulator sets, epilogue on the oldest", wps, in, out);
+        run2<9>("9 multiplies before the next chain, max tree beside it", wps, in, out);
     }
     for (int wps = 1; wps <= 2; wps++) {
         run<0>("0 MFMA only (4 dependent, K=64)", wps, in, out);
