@@ -311,6 +311,8 @@ def main():
                 "kernel": (("k_sweep_bf16" if n_iso == 8 else "k_sweep_bf16_1") if (B <= 8 or n_iso == 8) else "k_sweep_mfma1"),
                 "value": total_ranges / dt3, "unit": "range-block matches/s", "ms_per_step": dt3 / args.steps * 1e3,
                 "avg_launch_ms": ms3 / max(n3, 1), "speedup_vs_default": dt / dt3,
+                "mfma_roofline_frac": (pair_evals * 2.0 * n) / (ms3 / max(n3, 1) * 1e-3) / 1e12 /
+                                      (2500.0 if (B <= 8 or n_iso == 8) else 5000.0),
                 "note": "bit-identical codebooks (tests/test_gpu_mfma.py); inner products on v_mfma_f32_32x32x16_bf16 "
                         "(centred pixels are exact bf16) or, at B = 16 with 1 isometry, v_mfma_i32_32x32x32_i8. "
                         "Not the default because north_star asks for a VALU-only sweep (DESIGN.md section 6)."}
