@@ -1,4 +1,7 @@
-// fic_mfma.hip -- OPT-IN matrix-core sweeps ("sweep" = 3): k_sweep_mfma<NM> (8 iso) and k_sweep_mfma1<NM> (1 iso), B = 4/8/16.
+// fic_mfma.hip -- OPT-IN matrix-core sweeps with i8 operands: k_sweep_mfma<NM> (8 iso) and k_sweep_mfma1<NM> (1 iso), B = 4/8/16.
+// These were the round's first matrix-core kernels.  "sweep" = 3 now runs the bf16-operand kernels of fic_bf16.hip
+// wherever those are faster (B = 4/8, and B = 16 with 8 isometries) and k_sweep_mfma1<8> at B = 16 with 1 isometry;
+// "sweep" = 4 runs the kernels of this file at every block size (kept for comparison and tested to the same bar).
 // gfx950 (MI355X / CDNA4) only, wave64.  Compile with -ffp-contract=off: every float expression must round once
 // per operation exactly like the Java reference (FractalCompression.java = FC, Domainblock.java = DB).
 #include <hip/hip_runtime.h>
@@ -9,7 +12,7 @@
 #include "fic_devfn.h"
 
 // ---------------------------------------------------------------------------------------------
-// k_sweep_mfma<NM> : OPT-IN matrix-core variant of the full-pool sweep ("sweep" = 3; n_iso = 8; B = 4/8/16).
+// k_sweep_mfma<NM> : OPT-IN matrix-core variant of the full-pool sweep, i8 operands ("sweep" = 4; n_iso = 8; B = 4/8/16).
 //
 // north_star asks for a VALU-only sweep and k_sweep_fast is that kernel (and the default).  It
 // is pinned at the v_dot4 issue ceiling; the inner products of all (range copy,
@@ -222,8 +225,8 @@ __global__ __launch_bounds__(256) void k_sweep_mfma(MfmaArgs A)
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_sweep_mfma1 : OPT-IN matrix-core sweep for the reference algorithm (n_iso = 1), B = 4 / 8 / 16
-// ("sweep" = 3).  Same exactness scheme as k_sweep_mfma; the mapping is transposed:
+// k_sweep_mfma1 : OPT-IN matrix-core sweep for the reference algorithm (n_iso = 1), i8 operands, B = 4 / 8 / 16
+// ("sweep" = 4; "sweep" = 3 at B = 16).  Same exactness scheme as k_sweep_mfma; the mapping is transposed:
 //   rows (A) = 32 consecutive domain blocks, streamed; cols (B) = 32 range blocks, fixed in LDS.
 //   col = lane&31 is the lane's range block: its constants {K, A, negR} and its tau come from
 //   LDS with one ds_read_b128 per column tile (tau is raised there by the exact path with
