@@ -257,15 +257,64 @@ class FractalCompression:
         return cls.avgError
 
     @classmethod
-    def decode(cls, inputStream):   # FC:547-553
+    def decode(cls, inputStream):   # FC:547-553: readInt() isRGB, then the matching decoder on the rest of the stream
         data = inputStream.read() if hasattr(inputStream, "read") else bytes(inputStream)
         if len(data) >= 4 and int.from_bytes(data[:4], "big", signed=True) != 0:      # FC:549-552 -> decodeRGB
-            argb, avg, _, w, h = capi.decode_rgb_run(data, cls.device, float(cls.avgError))
-            cls.avgError = avg
-            return RasterImage(w, h, argb)
-        gray, avg, _ = capi.decode_gray_run(data, cls.device, float(cls.avgError))
+            return cls._decode_rgb(data)
+        return cls._decode_gray(data)
+
+    @classmethod
+    def _decode_gray(cls, run):
+        gray, avg, _ = capi.decode_gray_run(run, cls.device, float(cls.avgError))
         cls.avgError = avg
         return RasterImage.from_gray(gray)
+
+    @classmethod
+    def _decode_rgb(cls, run):
+        argb, avg, _, w, h = capi.decode_rgb_run(run, cls.device, float(cls.avgError))
+        cls.avgError = avg
+        return RasterImage(w, h, argb)
+
+    @classmethod
+    def decodeGreyScale(cls, inputStream):   # FC:356-421: the stream positioned AFTER the isRGB int (as FC.decode leaves it)
+        rest = inputStream.read() if hasattr(inputStream, "read") else bytes(inputStream)
+        return cls._decode_gray((0).to_bytes(4, "big") + rest)
+
+    @classmethod
+    def decodeRGB(cls, inputStream):   # FC:430-508: same convention
+        rest = inputStream.read() if hasattr(inputStream, "read") else bytes(inputStream)
+        return cls._decode_rgb((1).to_bytes(4, "big") + rest)
+
+    @classmethod
+    def generateKernel(cls, domainbloeckePerWidth, domainbloeckePerHeight, index):   # FC:84-100 (host integer logic)
+        wK = cls.widthKernel
+        dy = index // domainbloeckePerWidth - wK // 2
+        dx = index % domainbloeckePerWidth - wK // 2
+        dx, dy = max(dx, 0), max(dy, 0)
+        if dx + wK >= domainbloeckePerWidth:
+            dx = domainbloeckePerWidth - wK
+        if dy + wK >= domainbloeckePerHeight:
+            dy = domainbloeckePerHeight - wK
+        return [dy, dx]
+
+    @staticmethod
+    def generateGrayImage(width, height):   # FC:1142-1148
+        return RasterImage(width, height, np.full(width * height, np.int32(-8355712)))   # 0xff808080
+
+    _collage = None
+    _collageRGB = None
+
+    @classmethod
+    def getBestGeneratedCollage(cls, originalImage):   # FC:269-300: the collage of the last encodeGrayScale
+        if cls._collage is None or cls._collage.size != originalImage.width * originalImage.height:
+            raise FicError(-7, "getBestGeneratedCollage: no grey encode of this image size yet")
+        return RasterImage(originalImage.width, originalImage.height, cls._collage.copy())
+
+    @classmethod
+    def getBestGeneratedCollageRGB(cls, originalImage):   # FC:308-347
+        if cls._collageRGB is None or cls._collageRGB.size != originalImage.width * originalImage.height:
+            raise FicError(-7, "getBestGeneratedCollageRGB: no RGB encode of this image size yet")
+        return RasterImage(originalImage.width, originalImage.height, cls._collageRGB.copy())
 
     imageInfoRGB = None       # float32 [N_r][5] = {i_local, a, bR, bG, bB}   (FC:18,185)
     _lastRGB = None
@@ -276,8 +325,9 @@ class FractalCompression:
         r = capi.encode_rgb(image.argb, image.width, image.height, B, wK, cls.device, want_collage=True)
         cls.imageInfoRGB = np.stack([r["idx_local"].astype(np.float32), r["a"], r["bR"], r["bG"], r["bB"]], axis=1)
         cls._lastRGB = {"qrows": r["qrows"]}
+        cls._collageRGB = np.asarray(r["collage"], np.int32).reshape(-1).copy()
         cls.writeData(out, 1, image.width, image.height)              # FC:217
-        return RasterImage(image.width, image.height, r["collage"])    # FC:218
+        return cls.getBestGeneratedCollageRGB(image)                   # FC:218
 
     @classmethod
     def encodeGrayScale(cls, image, out):   # FC:109-162
@@ -289,9 +339,9 @@ class FractalCompression:
             cls.imageInfo = np.stack([r["idx_local"][0].astype(np.float32), r["a"][0], r["b"][0]], axis=1)
             cls.imageIso = r["iso"][0].copy()
             cls._last = {"qrows": r["qrows"][0].copy(), "w": image.width, "h": image.height, "B": B, "wK": wK}
+            cls._collage = np.asarray(enc.collage()[0], np.int32).reshape(-1).copy()
             cls.writeData(out, 0, image.width, image.height)          # FC:160
-            collage = enc.collage()[0]                                 # FC:161
-        return RasterImage(image.width, image.height, collage)
+        return cls.getBestGeneratedCollage(image)                      # FC:161
 
     @classmethod
     def writeData(cls, out, isRGB, width, height):   # FC:230-261

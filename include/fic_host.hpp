@@ -16,6 +16,7 @@
 #include <ostream>
 #include <stdexcept>
 #include <string>
+#include <array>
 #include <vector>
 
 #include "fic.h"
@@ -44,6 +45,26 @@ public:
 
     static inline float avgError = 0.0f;         // FractalCompression.java:20 -- never reset between decode calls
     static float getAvgError() { return avgError; }   // FractalCompression.java:22-24
+
+    // FractalCompression.java:84-100: window origin {dy, dx} of candidate-centre `index` (host integer logic).
+    static std::array<int, 2> generateKernel(int domainbloeckePerWidth, int domainbloeckePerHeight, int index)
+    {
+        int dy = index / domainbloeckePerWidth - widthKernel / 2;
+        int dx = index % domainbloeckePerWidth - widthKernel / 2;
+        if (dx < 0) dx = 0;
+        if (dy < 0) dy = 0;
+        if (dx + widthKernel >= domainbloeckePerWidth) dx = domainbloeckePerWidth - widthKernel;
+        if (dy + widthKernel >= domainbloeckePerHeight) dy = domainbloeckePerHeight - widthKernel;
+        return {dy, dx};
+    }
+
+    // FractalCompression.java:1142-1148
+    static RasterImage generateGrayImage(int width, int height)
+    {
+        RasterImage image(width, height);
+        for (auto& p : image.argb) p = (int32_t)0xff808080u;
+        return image;
+    }
 
     // FractalCompression.java:54-59.  Returns the collage image like the reference.
     static RasterImage encode(const RasterImage& input, std::ostream& out)

@@ -4,6 +4,7 @@
 //   host_mirror_test encode_argb <argb.raw i32>  w h B wK out.run collage.raw     (colour -> encodeRGB)
 //   host_mirror_test decode      <in.run> out_argb.raw                            (prints avgError)
 //   host_mirror_test synth       U|S w h seed out.raw                             (include/fic_synth.h; no GPU needed)
+//   host_mirror_test kernel      Dw Dh index wK                                   (prints generateKernel's dy dx; no GPU needed)
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -16,6 +17,12 @@ using FC = bvk_ss19::FractalCompression;
 
 static int run(int argc, char** argv)
 {
+    if (argc == 6 && !std::strcmp(argv[1], "kernel")) {
+        FC::widthKernel = std::atoi(argv[5]);
+        auto k = FC::generateKernel(std::atoi(argv[2]), std::atoi(argv[3]), std::atoi(argv[4]));
+        std::printf("%d %d\n", k[0], k[1]);
+        return 0;
+    }
     if (argc == 7 && !std::strcmp(argv[1], "synth")) {
         const int w = std::atoi(argv[3]), h = std::atoi(argv[4]);
         std::vector<uint8_t> img((size_t)w * h);

@@ -181,6 +181,29 @@ def test_drop_in_entry_point_and_collage(oracle):
     fc.blockgroesse, fc.widthKernel = 8, 2
 
 
+def test_mirror_public_methods_beside_encode_and_decode(oracle):
+    """The other public members of FractalCompression on the path: getBestGeneratedCollage (FC:269-300, what
+    encodeGrayScale returns), decodeGreyScale / decodeRGB (FC:356, 430: the stream positioned after the isRGB int)."""
+    g = IMAGES["lena64"]
+    fc = fic_amd.FractalCompression
+    fc.blockgroesse, fc.widthKernel, fc.n_iso = 4, 5, 1
+    img = fic_amd.RasterImage.from_gray(g)
+    out = io.BytesIO()
+    collage = fc.encode(img, out)
+    assert (fc.getBestGeneratedCollage(img).argb == collage.argb).all()
+    run = out.getvalue()
+    fc.avgError = np.float32(0.0)
+    a = fc.decode(io.BytesIO(run))
+    avg_a = fc.getAvgError()
+    fc.avgError = np.float32(0.0)
+    b = fc.decodeGreyScale(io.BytesIO(run[4:]))
+    assert (a.argb == b.argb).all() and fc.getAvgError() == avg_a
+    with pytest.raises(fic_amd.FicError):
+        fc.getBestGeneratedCollage(fic_amd.RasterImage(128, 128))
+    fc.blockgroesse, fc.widthKernel = 8, 2
+    fc.avgError = np.float32(0.0)
+
+
 def test_one_shot_c_entry_points(oracle):
     g = IMAGES["lena64"]
     ref = _oracle_encode(oracle, g, 4, 29, 1)

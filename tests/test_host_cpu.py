@@ -165,3 +165,34 @@ def test_synthetic_inputs_are_the_same_bytes_in_c_and_python(tmp_path, kind, w, 
     subprocess.check_call([drv, "synth", kind, str(w), str(h), hex(seed), str(out)])
     got = np.fromfile(out, np.uint8).reshape(h, w)
     assert (got == fic_amd.synth.image(kind, w, h, seed)).all()
+
+
+def test_mirror_generate_kernel_and_grey_image(oracle):
+    """FractalCompression.generateKernel (FC:84-100) and generateGrayImage (FC:1142-1148) of the Python mirror are host
+    logic; the oracle's restatement of the same Java lines agrees on random inputs."""
+    import ctypes as C
+    L = oracle.lib()
+    fc = fic_amd.FractalCompression
+    rng = np.random.default_rng(5)
+    keep = fc.widthKernel
+    try:
+        for _ in range(500):
+            Dw, Dh = int(rng.integers(1, 70)), int(rng.integers(1, 70))
+            wK = int(rng.integers(1, min(Dw, Dh) + 1))
+            idx = int(rng.integers(0, Dw * Dh))
+            dy, dx = C.c_int(), C.c_int()
+            L.fo_generate_kernel(Dw, Dh, idx, wK, C.byref(dy), C.byref(dx))
+            fc.widthKernel = wK
+            assert fc.generateKernel(Dw, Dh, idx) == [dy.value, dx.value]
+    finally:
+        fc.widthKernel = keep
+    img = fc.generateGrayImage(7, 3)
+    assert (img.width, img.height) == (7, 3) and (img.argb.view(np.uint32) == 0xFF808080).all()
+    import os
+    drv = os.path.join(os.path.dirname(__file__), "cpp", "host_mirror_test")       # the C++ mirror's generateKernel
+    if os.path.exists(drv):
+        for Dw, Dh, idx, wK in [(29, 29, 0, 5), (61, 61, 1830, 16), (13, 29, 200, 4), (125, 125, 15624, 125)]:
+            dy, dx = C.c_int(), C.c_int()
+            L.fo_generate_kernel(Dw, Dh, idx, wK, C.byref(dy), C.byref(dx))
+            out = subprocess.run([drv, "kernel", str(Dw), str(Dh), str(idx), str(wK)], capture_output=True, text=True).stdout.split()
+            assert [int(v) for v in out] == [dy.value, dx.value]
