@@ -867,6 +867,61 @@ int fic_decode_rgb_run(const uint8_t* run, int64_t len, int device, int32_t* arg
 }
 
 // ---- joint-RGB encode (encodeRGB FC:171-219) -----------------------------------------------------
+namespace {
+// Working set of the last one-shot RGB geometry: the GUI re-encodes the same image on every slider move
+// (RLEAppController.java:125-145), and 16 hipMalloc/hipFree cost more than a windowed search.  One slot; a call with
+// another geometry (or device) replaces it; fic_release_cache() frees it.
+struct RgbSet {
+    int device = -1, w = 0, h = 0, B = 0, wK = 0;
+    FicRgbBuffers b{};
+    FicRgbOutputs o{};
+    int32_t* collage = nullptr;
+    void free_all()
+    {
+        if (device >= 0) (void)hipSetDevice(device);
+        void* ptrs[] = {b.argb, b.scaled, b.pool_sum, b.pool_cf, b.pool_st, b.rng_t, b.rng_st, b.key, o.idx_local,
+                        o.idx_global, o.a, o.bR, o.bG, o.bB, o.qrows, collage};
+        for (void* p : ptrs)
+            if (p) (void)hipFree(p);
+        memset(&b, 0, sizeof(b));
+        memset(&o, 0, sizeof(o));
+        collage = nullptr;
+        device = -1;
+    }
+};
+std::mutex g_rgb_mu;
+RgbSet* g_rgb_set = nullptr;
+
+int rgb_set_alloc(RgbSet* r, const FicGeom& g, int device, int w, int h, int B, int wK)
+{
+    const size_t npix = (size_t)w * h, nr = (size_t)g.Nr, nd = (size_t)g.Nd, n = (size_t)g.n;
+    hipError_t e = hipSuccess;
+    auto M = [&](void** p, size_t bytes) { if (e == hipSuccess) e = hipMalloc(p, bytes); };
+    r->device = device; r->w = w; r->h = h; r->B = B; r->wK = wK;
+    M((void**)&r->b.argb, npix * 4);
+    M((void**)&r->b.scaled, (size_t)g.Ws * g.Hs * 4);
+    M((void**)&r->b.pool_sum, nd * n * 2);
+    if (g.full && g.B <= 8) M((void**)&r->b.pool_cf, nd * n * 4);      // fast full-search sweep (k_sweep_rgb_fast)
+    M((void**)&r->b.pool_st, nd * sizeof(FicRgbDomStat));
+    M((void**)&r->b.rng_t, nr * n * 2);
+    M((void**)&r->b.rng_st, nr * sizeof(FicRgbRngStat));
+    M((void**)&r->b.key, nr * 8);
+    M((void**)&r->o.idx_local, nr * 4);
+    M((void**)&r->o.idx_global, nr * 4);
+    M((void**)&r->o.a, nr * 4);
+    M((void**)&r->o.bR, nr * 4);
+    M((void**)&r->o.bG, nr * 4);
+    M((void**)&r->o.bB, nr * 4);
+    M((void**)&r->o.qrows, nr * 20);
+    M((void**)&r->collage, npix * 4);
+    if (e != hipSuccess) {
+        r->free_all();
+        return fail(FIC_E_HIP, "fic_encode_rgb_argb: %s", hipGetErrorString(e));
+    }
+    return FIC_OK;
+}
+}  // namespace
+
 int fic_encode_rgb_argb(const int32_t* argb, int w, int h, int B, int wK, int device, int32_t* idx_local, float* a,
                         float* bR, float* bG, float* bB, int32_t* qrows5, int32_t* collage_argb)
 {
@@ -877,50 +932,55 @@ int fic_encode_rgb_argb(const int32_t* argb, int w, int h, int B, int wK, int de
     int ndev = fic_device_count();
     if (ndev <= 0 || device < 0 || device >= ndev) return fail(FIC_E_NO_DEVICE, "no HIP device %d (this library has no CPU path)", device);
     HIP_TRY(hipSetDevice(device));
-    FicRgbBuffers b;
-    FicRgbOutputs o;
-    memset(&b, 0, sizeof(b));
-    memset(&o, 0, sizeof(o));
-    int32_t* d_collage = nullptr;
-    const size_t npix = (size_t)w * h, nr = (size_t)g.Nr, nd = (size_t)g.Nd, n = (size_t)g.n;
-    hipError_t e = hipSuccess;
-    auto M = [&](void** p, size_t bytes) { if (e == hipSuccess) e = hipMalloc(p, bytes); };
-    M((void**)&b.argb, npix * 4);
-    M((void**)&b.scaled, (size_t)g.Ws * g.Hs * 4);
-    M((void**)&b.pool_sum, nd * n * 2);
-    if (g.full && g.B <= 8) M((void**)&b.pool_cf, nd * n * 4);      // fast full-search sweep (k_sweep_rgb_fast)
-    M((void**)&b.pool_st, nd * sizeof(FicRgbDomStat));
-    M((void**)&b.rng_t, nr * n * 2);
-    M((void**)&b.rng_st, nr * sizeof(FicRgbRngStat));
-    M((void**)&b.key, nr * 8);
-    M((void**)&o.idx_local, nr * 4);
-    M((void**)&o.idx_global, nr * 4);
-    M((void**)&o.a, nr * 4);
-    M((void**)&o.bR, nr * 4);
-    M((void**)&o.bG, nr * 4);
-    M((void**)&o.bB, nr * 4);
-    M((void**)&o.qrows, nr * 20);
-    if (collage_argb) M((void**)&d_collage, npix * 4);
-    if (e == hipSuccess) e = hipMemcpy(b.argb, argb, npix * 4, hipMemcpyHostToDevice);
+    // take the cached working set if it fits, else build one (concurrent callers each get their own)
+    RgbSet* r = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_rgb_mu);
+        if (g_rgb_set && g_rgb_set->device == device && g_rgb_set->w == w && g_rgb_set->h == h && g_rgb_set->B == B &&
+            g_rgb_set->wK == wK) {
+            r = g_rgb_set;
+            g_rgb_set = nullptr;
+        }
+    }
+    if (!r) {
+        r = new RgbSet();
+        rc = rgb_set_alloc(r, g, device, w, h, B, wK);
+        if (rc) { delete r; return rc; }
+    }
+    const size_t npix = (size_t)w * h, nr = (size_t)g.Nr;
+    hipError_t e = hipMemcpy(r->b.argb, argb, npix * 4, hipMemcpyHostToDevice);
     if (e != hipSuccess) rc = fail(FIC_E_HIP, "fic_encode_rgb_argb: %s", hipGetErrorString(e));
-    if (rc == FIC_OK && fic_launch_rgb_encode(b, o, d_collage, g, nullptr)) rc = fail(FIC_E_HIP, "RGB kernel launch failed");
+    if (rc == FIC_OK && fic_launch_rgb_encode(r->b, r->o, collage_argb ? r->collage : nullptr, g, nullptr))
+        rc = fail(FIC_E_HIP, "RGB kernel launch failed");
     auto D = [&](void* dst, const void* src, size_t bytes) {
         if (rc == FIC_OK && dst) {
             hipError_t e2 = hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost);
             if (e2 != hipSuccess) rc = fail(FIC_E_HIP, "fic_encode_rgb_argb: %s", hipGetErrorString(e2));
         }
     };
-    D(idx_local, o.idx_local, nr * 4);
-    D(a, o.a, nr * 4);
-    D(bR, o.bR, nr * 4);
-    D(bG, o.bG, nr * 4);
-    D(bB, o.bB, nr * 4);
-    D(qrows5, o.qrows, nr * 20);
-    D(collage_argb, d_collage, npix * 4);
-    void* ptrs[] = {b.argb, b.scaled, b.pool_sum, b.pool_cf, b.pool_st, b.rng_t, b.rng_st, b.key, o.idx_local, o.idx_global,
-                    o.a, o.bR, o.bG, o.bB, o.qrows, d_collage};
-    for (void* p : ptrs)
-        if (p) (void)hipFree(p);
+    D(idx_local, r->o.idx_local, nr * 4);
+    D(a, r->o.a, nr * 4);
+    D(bR, r->o.bR, nr * 4);
+    D(bG, r->o.bG, nr * 4);
+    D(bB, r->o.bB, nr * 4);
+    D(qrows5, r->o.qrows, nr * 20);
+    D(collage_argb, r->collage, npix * 4);
+    RgbSet* drop = nullptr;
+    if (rc == FIC_OK) {
+        std::lock_guard<std::mutex> lk(g_rgb_mu);
+        drop = g_rgb_set;
+        g_rgb_set = r;
+    } else {
+        drop = r;
+    }
+    if (drop) {
+        const std::string keep = g_err;
+        const int keep_code = g_err_code;
+        drop->free_all();
+        delete drop;
+        g_err = keep;
+        g_err_code = keep_code;
+    }
     return rc;
 }
 
@@ -969,6 +1029,16 @@ void fic_release_cache(void)
         drop.swap(g_cache);
     }
     for (fic_ctx* c : drop) fic_ctx_destroy(c);
+    RgbSet* r = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_rgb_mu);
+        r = g_rgb_set;
+        g_rgb_set = nullptr;
+    }
+    if (r) {
+        r->free_all();
+        delete r;
+    }
 }
 
 int fic_encode_gray_argb(const int32_t* argb, int w, int h, int B, int wK, int n_iso, int device, int32_t* idx_local,

@@ -78,8 +78,8 @@ FIC_API int fic_encode_gray_argb(const int32_t* argb, int w, int h, int B, int w
 FIC_API int fic_encode_gray_u8(const uint8_t* gray, int w, int h, int B, int wK, int n_iso, int device,
                                int32_t* idx_local, float* a, float* b, int32_t* iso, int32_t* qrows);
 
-/* The one-shot entries keep the device working sets of the last few geometries (the GUI re-encodes
- * the same image on every slider move, RLEAppController.java:125-145); this frees them. */
+/* The one-shot entries (grey and RGB) keep the device working sets of the last few geometries (the GUI
+ * re-encodes the same image on every slider move, RLEAppController.java:125-145); this frees them. */
 FIC_API void fic_release_cache(void);
 
 /* writeData, grey branch (FractalCompression.java:230-246): big-endian int32 header
