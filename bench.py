@@ -106,7 +106,7 @@ def main():
                     help="synthetic input: U = iid bytes (the quoted distribution), S = flat tiles + noise, "
                          "lena = LenaGrey.png tiled/cropped to size with a per-image shift (robustness checks)")
     ap.add_argument("--chunks", type=int, default=0)
-    ap.add_argument("--sweep", type=int, default=0, choices=[0, 2, 3, 4],
+    ap.add_argument("--sweep", type=int, default=0, choices=[0, 2, 3, 4, 5],
                     help="0/2 = VALU sweep k_sweep_fast (default, north_star's design); 3 = opt-in matrix-core sweep "
                          "(bf16 operands; i8 at B = 16 with 1 isometry); 4 = matrix-core sweep with i8 operands at every B")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -236,6 +236,11 @@ def main():
         # n/4 v_dot4 per pair evaluation, plus per (range, domain): 1 iso -> 2 (base) + mul + cvt + cmp = 5;
         # 8 iso -> 2 (base) + mul + cvt + 8 (max3/min3 reduction of the 8 copies) + sub + 2 cmp = 15, shared by 8
         valu_per_eval = n / 4 + (15.0 / 8.0 if n_iso == 8 else 5.0)
+        kernel_name = "k_sweep_fast"
+        if info["sweep_kind"] == 5:
+            # k_sweep_d4: (n + n/2) / 2 v_dot2c + 54 other VALU per (range, domain), shared by the 8 copies (ISA count at B = 8)
+            valu_per_eval = ((n + n // 2) / 2 + 53.0) / 8.0
+            kernel_name = "k_sweep_d4"
         valu_frac = pair_evals * valu_per_eval / 64.0 / (avg_ms * 1e-3) / VALU_WAVE_INSTR_PEAK
         traffic, traffic_note = None, None
         try:   # HBM-side bytes per sweep launch from the committed rocprofv3 PMC passes (profiles/traffic.json)
@@ -251,7 +256,9 @@ def main():
             "value": value, "unit": "range-block matches/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": scaling, "vs_baseline": None, "dtype": "u8",
-            "dtype_detail": "u8 pixels, v_dot4_u32_u8 -> exact i32 covariances, f32 prune test, f64/f32 Java epilogue",
+            "dtype_detail": ("u8 pixels -> i16 group-Fourier slots of the 8 isometries, v_dot2c_i32_i16 -> exact i32 covariances, "
+                             "f32 prune test, f64/f32 Java epilogue") if info["sweep_kind"] == 5 else
+                            "u8 pixels, v_dot4_u32_u8 -> exact i32 covariances, f32 prune test, f64/f32 Java epilogue",
             "data": "synthetic",
             "config": {"workload": wl["desc"] if args.dist == "U" else wl["desc"].replace("synthetic grey U", f"grey {args.dist}"),
                        "dist": args.dist, "image": f"{W}x{H}", "B": B, "n_iso": n_iso, "wK": core.wK,
@@ -260,7 +267,7 @@ def main():
             "pair_evals_per_s": pair_evals * sweep_n / (sweep_ms * 1e-3) if sweep_ms > 0 else None,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,
-                         "kernel": "k_sweep_fast", "avg_launch_ms": avg_ms, "launches": sweep_n,
+                         "kernel": kernel_name, "avg_launch_ms": avg_ms, "launches": sweep_n,
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "note": "algorithmic bytes = ranges x N_d x (n+8); each wave keeps 64 range blocks in VGPRs "
                                  "and reads a pool block once for all of them, so frac > 1 means the sweep is past the "
@@ -271,7 +278,7 @@ def main():
                              "issue rate of v_dot4_u32_u8 (profiles/r01_valu_issue_rate_microbench.txt); PMC: "
                              "SQ_ACTIVE_INST_VALU = 96% of kernel cycles (profiles/r01a_cfg2_pmc_summary.txt)"},
         }
-        if info["sweep_kind"] >= 3:
+        if info["sweep_kind"] in (3, 4):
             # opt-in matrix-core sweeps.  "sweep" = 3 at B = 4/8 (and B = 16 with 8 isometries): centred pixels as exact bf16 operands of
             # v_mfma_f32_32x32x16_bf16 (dense bf16 peak 2.5 PFLOP/s); otherwise u8 shifted to i8 on
             # v_mfma_i32_32x32x32_i8 (dense i8 peak 5.0 PetaOP/s) -- MI355X_MICROARCH.md "Matrix cores".
@@ -292,7 +299,7 @@ def main():
             out["valu"] = {"bound": "valu-issue (epilogue)", "valu_instr_per_pair_eval": vpe,
                            "frac": pair_evals * vpe / 64.0 / (avg_ms * 1e-3) / VALU_WAVE_INSTR_PEAK,
                            "peak_wave_instr_per_s": VALU_WAVE_INSTR_PEAK}
-        if info["sweep_kind"] == 2 and world == 1 and not args.no_alt:
+        if info["sweep_kind"] in (2, 5) and world == 1 and not args.no_alt:
             # Same workload, same buffers, through the opt-in matrix-core sweep: reported beside, never as `value`.
             core.set_option("sweep", 3)
             for _ in range(args.warmup):
@@ -305,7 +312,7 @@ def main():
             torch.cuda.synchronize()
             dt3 = time.perf_counter() - t1
             ms3, n3 = core.sweep_time(reset=True)
-            core.set_option("sweep", 0)
+            core.set_option("sweep", args.sweep)
             out["opt_in_matrix_core"] = {
                 "how": "bench.py --sweep 3 / fic_ctx_set_option(ctx, \"sweep\", 3)",
                 "kernel": (("k_sweep_bf16" if n_iso == 8 else "k_sweep_bf16_1") if (B <= 8 or n_iso == 8) else "k_sweep_mfma1"),

@@ -99,6 +99,8 @@ struct fic_ctx {
     void* mfma_sw = nullptr;
     int* mfma_rconst = nullptr;
     int mfma_bf16 = 0;               // operand type the fragment stores were built for
+    uint32_t* d4_rng = nullptr;      // k_sweep_d4: range / domain slots of the group-Fourier form (n_iso = 8, B = 8 / 16)
+    uint32_t* d4_pool = nullptr;
     bool have_input = false;
     bool encoded_any = false;
     hipStream_t last_stream = nullptr;
@@ -124,7 +126,7 @@ int ctx_free_all(fic_ctx* c)
     (void)hipSetDevice(c->device);
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
     c->ev.clear();
-    void* ptrs[] = {c->gray_own, c->argb_stage, c->collage, c->decoded, c->mfma_poolB, c->mfma_rngA, c->mfma_sw, c->mfma_rconst, c->b.scaled, c->b.pool_pix, c->b.pool_st, c->b.pool_var,
+    void* ptrs[] = {c->gray_own, c->argb_stage, c->collage, c->decoded, c->mfma_poolB, c->mfma_rngA, c->mfma_sw, c->mfma_rconst, c->d4_rng, c->d4_pool, c->b.scaled, c->b.pool_pix, c->b.pool_st, c->b.pool_var,
                     c->b.pool_s64, c->b.rng_pix, c->b.rng_st, c->b.key, c->o.idx_local, c->o.idx_global, c->o.iso,
                     c->o.a, c->o.b, c->o.err, c->o.qrows};
     for (void* p : ptrs)
@@ -238,6 +240,46 @@ int valu_sweep(fic_ctx* c, int tile0, int ntiles, hipStream_t s, int* nchunks_ou
     chunk_len = (chunk_len + 1) & ~1;              // even: the sweep consumes blocks in pairs
     nchunks = (g.Nd + chunk_len - 1) / chunk_len;
     if (fic_launch_sweep_fast(c->b, g, tile0, ntiles, chunk_len, nchunks, s)) return fail(FIC_E_HIP, "k_sweep_fast launch failed");
+    *nchunks_out = nchunks;
+    return FIC_OK;
+}
+
+// VALU sweep for n_iso = 8 with the isometries taken algebraically (k_sweep_d4, fic_d4.hip): slot prep + sweep.
+int d4_available(const FicGeom& g) { return g.full && g.n_iso == 8 && g.NR == 1 && fic_d4_words(g.B) > 0; }
+int d4_prep(fic_ctx* c, hipStream_t s)
+{
+    const FicGeom& g = c->g;
+    const size_t NW = (size_t)fic_d4_words(g.B), P = (size_t)g.planes;
+    if (!c->d4_rng) {
+        HIP_TRY(hipMalloc((void**)&c->d4_rng, P * g.tiles * NW * 64 * 4));
+        HIP_TRY(hipMalloc((void**)&c->d4_pool, P * g.Nd_pad * NW * 4));
+    }
+    if (fic_launch_d4_prep(c->b, c->d4_rng, c->d4_pool, g, s)) return fail(FIC_E_HIP, "k_range_d4 / k_pool_d4 launch failed");
+    return FIC_OK;
+}
+int d4_sweep(fic_ctx* c, int tile0, int ntiles, hipStream_t s, int* nchunks_out)
+{
+    const FicGeom& g = c->g;
+    const long long base_waves = (long long)ntiles * g.planes;
+    int nchunks = c->opt_chunks;
+    if (nchunks <= 0) {                                // same policy as valu_sweep
+        long long want = (49152 + base_waves - 1) / base_waves;
+        long long cap = g.Nd / 4096;
+        if (cap < 1) cap = 1;
+        long long nc = want < cap ? want : cap;
+        if (base_waves * nc < 4096) {
+            long long cap2 = g.Nd / 512;
+            if (cap2 < 1) cap2 = 1;
+            long long fill = (4096 + base_waves - 1) / base_waves;
+            nc = fill < cap2 ? fill : cap2;
+        }
+        nchunks = (int)(nc < 1 ? 1 : nc);
+    }
+    if (nchunks > g.Nd) nchunks = g.Nd;
+    const int chunk_len = (g.Nd + nchunks - 1) / nchunks;
+    nchunks = (g.Nd + chunk_len - 1) / chunk_len;
+    if (fic_launch_sweep_d4(c->b, c->d4_rng, c->d4_pool, g, tile0, ntiles, chunk_len, nchunks, s))
+        return fail(FIC_E_HIP, "k_sweep_d4 launch failed");
     *nchunks_out = nchunks;
     return FIC_OK;
 }
@@ -520,7 +562,9 @@ int fic_ctx_encode(fic_ctx* c, int range_begin, int range_count, void* hip_strea
     // sweep
     int kind = c->opt_sweep;
     if (kind == 0) {
-        kind = g.full ? 2 : 1;
+        // full search: the VALU sweep; with 8 isometries at B = 8 its group-Fourier form (k_sweep_d4: 48 v_dot2c per pair
+        // instead of 128 v_dot4, same integers) -- "sweep" = 2 still selects k_sweep_fast there
+        kind = !g.full ? 1 : d4_available(g) ? 5 : 2;
         // FIC_SWEEP=3 opts the whole process into the matrix-core sweep wherever it is built (same results);
         // other geometries keep the VALU sweep.  An explicit fic_ctx_set_option("sweep", ...) wins.
         const char* env = getenv("FIC_SWEEP");
@@ -542,11 +586,15 @@ int fic_ctx_encode(fic_ctx* c, int range_begin, int range_count, void* hip_strea
                              (size_t)ntiles * tsz * sizeof(unsigned long long), (size_t)g.planes, s));
     int nchunks = 1;
     int rc = FIC_OK;
-    if (kind >= 3) rc = matrix_core_prep(c, kind, s);              // fragment prep belongs to pool build / range prep: not timed
+    if (kind == 5 && !d4_available(g)) return fail(FIC_E_ARGUMENT, "sweep 5 (k_sweep_d4) needs full search, n_iso = 8 and B = 8 or 16");
+    if (kind == 5) rc = d4_prep(c, s);
+    else if (kind >= 3) rc = matrix_core_prep(c, kind, s);              // fragment prep belongs to pool build / range prep: not timed
     if (rc == FIC_OK) rc = time_begin(c, s);
     if (rc == FIC_OK) {
         if (kind == 1) {
             if (fic_launch_sweep_generic(c->b, g, range_begin, range_count, s)) rc = fail(FIC_E_HIP, "k_sweep_generic launch failed");
+        } else if (kind == 5) {
+            rc = d4_sweep(c, tile0, tile1 - tile0, s, &nchunks);
         } else if (kind >= 3) {
             rc = matrix_core_sweep(c, kind, tile0, tile1, s, &nchunks);
         } else {
@@ -620,8 +668,8 @@ int fic_ctx_set_option(fic_ctx* c, const char* name, int value)
 {
     if (!c || !name) return fail(FIC_E_ARGUMENT, "fic_ctx_set_option: null argument");
     if (!strcmp(name, "sweep")) {
-        if (value < 0 || value > 4)
-            return fail(FIC_E_ARGUMENT, "sweep must be 0 (auto), 1 (generic), 2 (fast, VALU), 3 (matrix-core) or 4 (matrix-core, i8 operands)");
+        if (value < 0 || value > 5)
+            return fail(FIC_E_ARGUMENT, "sweep must be 0 (auto), 1 (generic), 2 (fast, VALU), 3 (matrix-core), 4 (matrix-core, i8 operands) or 5 (VALU, group-Fourier isometries)");
         c->opt_sweep = value;
     } else if (!strcmp(name, "chunks")) {
         if (value < 0) return fail(FIC_E_ARGUMENT, "chunks must be >= 0");

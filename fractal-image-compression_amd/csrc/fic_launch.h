@@ -99,6 +99,11 @@ int fic_launch_sweep_bf16(const FicBuffers& b, const void* poolF, const void* po
 int fic_launch_sweep_bf16_1(const FicBuffers& b, const void* poolF, const void* pool_w, const void* rngF, const FicGeom& g,
                             int ct_begin, int ct_end, int ndtiles, int ndtiles_alloc, int nctiles_alloc, int tiles_per_chunk,
                             int nchunks, hipStream_t s);
+// VALU sweep with algebraic isometries (fic_d4.hip): n_iso = 8, B = 8 / 16
+int fic_d4_words(int B);             // dwords (dot2 pairs) per block in the group-Fourier form, 0 if not built for B
+int fic_launch_d4_prep(const FicBuffers& b, uint32_t* rng_d4, uint32_t* pool_d4, const FicGeom& g, hipStream_t s);
+int fic_launch_sweep_d4(const FicBuffers& b, const uint32_t* rng_d4, const uint32_t* pool_d4, const FicGeom& g, int tile0,
+                        int ntiles, int chunk_len, int nchunks, hipStream_t s);
 int fic_launch_decode_iteration_rgb(int32_t* scaled, int32_t* image, const int32_t* qrows5, FicDecodeState* state,
                                     int counter, const FicGeom& g, hipStream_t s);
 

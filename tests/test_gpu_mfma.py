@@ -141,8 +141,8 @@ def test_fic_sweep_environment_opt_in(tmp_path):
         k, q = str(tmp_path / f"k_{tag}.npy"), str(tmp_path / f"q_{tag}.npy")
         subprocess.check_call([sys.executable, "-c", code, k, q], env={**os.environ, **env})
         res[tag] = (np.load(k), np.load(q))
-    assert res["valu"][0].tolist() == [2, 2, 2, 2]
-    assert res["mfma"][0].tolist() == [2, 3, 3, 3]       # the single 256x256 image stays on the VALU sweep
+    assert res["valu"][0].tolist() == [5, 5, 2, 2]       # default VALU sweeps: k_sweep_d4 at B = 8 with 8 isometries, else k_sweep_fast
+    assert res["mfma"][0].tolist() == [5, 3, 3, 3]       # the single 256x256 image stays on the VALU sweep
     assert (res["valu"][1] == res["mfma"][1]).all()
 
 

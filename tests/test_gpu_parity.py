@@ -505,6 +505,8 @@ def test_seeded_fuzz_geometries_windows_sweeps(oracle):
         sweeps = [1]
         if wK == Dw == Dh:
             sweeps += [2, 3, 4]                         # VALU, matrix-core (bf16 / i8 by block size), matrix-core i8
+            if B == 8 and n_iso == 8:
+                sweeps.append(5)                        # VALU with algebraic isometries (k_sweep_d4)
         for sweep in sweeps:
             got = fic_amd.encode_gray(g, B, wK, n_iso, sweep=sweep, chunks=int(rng.integers(0, 4)) if sweep >= 2 else 0)
             try:

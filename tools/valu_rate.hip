@@ -57,6 +57,22 @@ __global__ void k(uint32_t* out, unsigned long long* clk, int iters, uint32_t sv
 #define X(i) asm volatile("v_mul_f32 %0, %1, %0" : "+v"(fa[i]) : "s"(s));
                 REP8(X)
 #undef X
+            } else if (OP == 9) {
+#define X(i) asm volatile("v_dot2c_i32_i16 %0, %1, %2" : "+v"(a[i]) : "s"(s), "v"(b));
+                REP8(X)
+#undef X
+            } else if (OP == 10) {
+#define X(i) asm volatile("v_dot2c_i32_i16 %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(b));
+                REP8(X)
+#undef X
+            } else if (OP == 11) {
+#define X(i) asm volatile("v_max3_i32 %0, %1, %2, %0" : "+v"(a[i]) : "v"(b), "v"(a[(i + 1) & 7]));
+                REP8(X)
+#undef X
+            } else if (OP == 12) {
+#define X(i) asm volatile("v_sub_u32 %0, %1, %0" : "+v"(a[i]) : "v"(b));
+                REP8(X)
+#undef X
             }
         }
     }
@@ -98,7 +114,7 @@ void run(const char* name, int waves_per_simd)
 
 int main()
 {
-    for (int w : {1, 2, 4, 8}) {
+    for (int w : {2, 4, 8}) {
         run<0>("v_dot4_u32_u8 v,v", w);
         run<1>("v_dot4_u32_u8 v,s", w);
         run<2>("v_fma_f32", w);
@@ -108,6 +124,10 @@ int main()
         run<6>("v_cvt_f32_i32", w);
         run<7>("v_cmp_nle_f32 |v|,v", w);
         run<8>("v_mul_f32 s,v", w);
+        run<9>("v_dot2c_i32_i16 s,v", w);
+        run<10>("v_dot2c_i32_i16 v,v", w);
+        run<11>("v_max3_i32", w);
+        run<12>("v_sub_u32", w);
     }
     return 0;
 }
