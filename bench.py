@@ -275,6 +275,10 @@ def main():
             "valu": {"bound": "valu-issue (the true bound of this kernel)", "frac": valu_frac,
                      "valu_instr_per_pair_eval": valu_per_eval, "peak_wave_instr_per_s": VALU_WAVE_INSTR_PEAK,
                      "note": "peak = 1 wave64 VALU instruction / 4 cycles / SIMD x 1024 SIMDs x 2.4 GHz, the measured "
+                             "issue rate of v_dot4_u32_u8 and v_dot2c_i32_i16 (profiles/r01_valu_issue_rate_microbench.txt); "
+                             "k_sweep_d4's 53 non-dot instructions are mostly 2-cycle adds, so its frac is an upper estimate"
+                             if info["sweep_kind"] == 5 else
+                             "peak = 1 wave64 VALU instruction / 4 cycles / SIMD x 1024 SIMDs x 2.4 GHz, the measured "
                              "issue rate of v_dot4_u32_u8 (profiles/r01_valu_issue_rate_microbench.txt); PMC: "
                              "SQ_ACTIVE_INST_VALU = 96% of kernel cycles (profiles/r01a_cfg2_pmc_summary.txt)"},
         }

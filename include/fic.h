@@ -157,7 +157,9 @@ FIC_API int fic_decode_rgb_run(const uint8_t* run, int64_t len, int device, int3
 FIC_API int fic_ctx_decode_host(fic_ctx* ctx, uint8_t* gray_out, float* avg_error_out, int* iterations_out);
 
 /* Tuning / instrumentation knobs:
- *   "sweep"       0 auto (VALU fast kernel for full search, generic otherwise), 1 generic, 2 fast,
+ *   "sweep"       0 auto: windowed search -> generic kernel; full search -> the VALU sweep (k_sweep_d4, the
+ *                     group-Fourier form, for 8 isometries at B = 8; k_sweep_fast otherwise)
+ *                 1 generic, 2 k_sweep_fast (VALU, v_dot4), 5 k_sweep_d4 (VALU, v_dot2c; n_iso = 8, B = 8 only),
  *                 3 = opt-in matrix-core sweep (B = 4/8/16, n_iso = 1 or 8, full search; same results): bf16
  *                     operands (centred pixels are exact bf16) at B = 4/8 and at B = 16 with 8 isometries, i8
  *                     operands at B = 16 with 1 isometry -- whichever is faster

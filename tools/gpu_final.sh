@@ -16,12 +16,14 @@ export TMPDIR=/tmp
 cd /tmp
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_prof -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $O/${TAG}_prof_bench.json 2> $O/${TAG}_prof.err || { tail -20 $O/${TAG}_prof.err; exit 1; }
 find $O/${TAG}_prof -name "*kernel_stats*" | head -2
-for c in FETCH_SIZE WRITE_SIZE; do
-  timeout -k 10 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/${TAG}_pmc_$c -- python3 $R/bench.py --sweep 3 --steps 3 --warmup 1 --no-cpu-baseline > $O/${TAG}_pmc_$c.json 2> $O/${TAG}_pmc_$c.err || { tail -5 $O/${TAG}_pmc_$c.err; exit 1; }
+for c in FETCH_SIZE WRITE_SIZE "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE"; do
+  n=$(echo $c | cut -d" " -f1)
+  # the default run times the default sweep and, beside it, the matrix-core sweep: both kernels appear in the counters
+  timeout -k 10 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/${TAG}_pmc_$n -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/${TAG}_pmc_$n.json 2> $O/${TAG}_pmc_$n.err || { tail -5 $O/${TAG}_pmc_$n.err; exit 1; }
 done
 python3 - <<PY
 import csv, glob, collections
-for name in ["FETCH_SIZE","WRITE_SIZE"]:
+for name in ["FETCH_SIZE","WRITE_SIZE","SQ_INSTS_VALU"]:
     for f in glob.glob("$O/${TAG}_pmc_%s/**/*counter_collection.csv" % name, recursive=True):
         acc = collections.defaultdict(lambda: [0.0,0])
         for row in csv.DictReader(open(f)):

@@ -15,7 +15,7 @@ print('%-44s value %.4g %s  ms/step %.4g  sweep %.4g ms  kernel %s  roofline(%s)
 " "$1" "$2"; }
 for spec in "cfg2:10:2" "cfg2x1:20:5" "cfg4:2:1" "cfg4iso1:3:1" "cfg3:2:1" "cfg5:2:1"; do
   IFS=: read wl st wu <<< "$spec"
-  for sw in 2 3; do
+  for sw in 0 2 3; do
     f=$O/${TAG}_${wl}_s${sw}.json
     timeout -k 10 300 python bench.py --workload $wl --sweep $sw --steps $st --warmup $wu --no-cpu-baseline --no-alt > $f 2> $O/${TAG}_err.txt || { tail -5 $O/${TAG}_err.txt; exit 1; }
     line $f "$wl sweep=$sw" >> $O/${TAG}_matrix.txt
