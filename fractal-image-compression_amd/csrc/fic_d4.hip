@@ -24,6 +24,8 @@
 #include "fic_d4_tables.h"
 
 typedef short s16x2 __attribute__((ext_vector_type(2)));
+#define D4_BIAS 0x10000000u               // 2^28 > every |T[acc]| (<= 16 slots * 2040 * 4080 < 2^27)
+#define D4_BIAS_B 0x40000000u             // 2^30 > |T0 + T1|, |T2 + T3| (< 2^28 + 2^26 with the mean correction in T0)
 
 template <int B> struct D4;
 template <> struct D4<8> {
@@ -187,10 +189,12 @@ __global__ __launch_bounds__(256) void k_sweep_d4(D4Args A)
         // consecutive v_dot2c are independent, and each half of the record can be re-requested (record d + 1; the pool
         // tail is padded: Nd_pad > Nd) as soon as its last v_dot2c has been issued.
         int T[8];
-        T[0] = 16 * (__mul24(neg_rM, Sd) + __mul24(neg_rem, dM));
+        T[0] = 16 * (__mul24(neg_rM, Sd) + __mul24(neg_rem, dM)) + (int)D4_BIAS_B;
+        T[2] = (int)D4_BIAS_B;
+        T[4] = T[5] = T[6] = T[7] = (int)D4_BIAS;
         auto dot = [&](int w) {
             const int a = D4<B>::acc[w];
-            bool first = a != 0;
+            bool first = a == 1 || a == 3;              // T1, T3 start from their first product; the others are preloaded
 #pragma unroll
             for (int v = 0; v < w; v++) first = first && (D4<B>::acc[v] != a);
             const int c = first ? 0 : T[a];
@@ -210,23 +214,36 @@ __global__ __launch_bounds__(256) void k_sweep_d4(D4Args A)
         for (int w = NW / 2; w < NW; w++) pv[w] = pcur[w];
         sc = st[d + 1];
         __builtin_amdgcn_sched_barrier(0);
-        const int u0 = T[0] + T[1], u1 = T[0] - T[1], x0 = T[2] + T[3], x1 = T[2] - T[3];
-        const int b[4] = {u0 + x0, u0 - x0, u1 + x1, u1 - x1};
-        const int e[4] = {T[4] + T[5], T[4] - T[5], T[6] + T[7], T[6] - T[7]};
-        // base i pairs with e term ej: the two copies k with form[k].b == i are b[i] + e[j] and b[i] - e[j]
-        int hi = -2147483647 - 1, lo = 2147483647;
+        // Prune test: the largest |16*cov_k| over the 8 copies is max_i (|b_i| + |e_j(i)|)  (|b + e| and |b - e| peak at
+        // |b| + |e|), with b = u +/- x and e = T4 +/- T5 or T6 +/- T7.  T0 and T2 carry a bias of 2^30, T4..T7 one of 2^28
+        // (every |sum| stays below its bias), so each |p +/- q| is an UNSIGNED absolute difference and v_sad_u32 adds the
+        // other magnitude in the same instruction: two v_sad_u32 per i.
+        const uint32_t u0 = (uint32_t)(T[0] + T[1]), u1 = (uint32_t)(T[0] - T[1]);            // u + 2^30
+        const uint32_t x0 = (uint32_t)(T[2] + T[3]), x1 = (uint32_t)(T[2] - T[3]);            // x + 2^30
+        const uint32_t nx0 = 2u * D4_BIAS_B - x0, nx1 = 2u * D4_BIAS_B - x1;                  // -x + 2^30
+        const uint32_t t4 = (uint32_t)T[4], t5 = (uint32_t)T[5], t6 = (uint32_t)T[6], t7 = (uint32_t)T[7];
+        const uint32_t n5 = 2u * D4_BIAS - t5, n7 = 2u * D4_BIAS - t7;                        // -T + 2^28
+        uint32_t m = 0;
 #pragma unroll
         for (int k = 0; k < 8; k++)
             if (D4<B>::form[k][2] > 0) {
-                const int bi = D4<B>::form[k][0], ae = abs(e[D4<B>::form[k][1]]);
-                hi = max(hi, b[bi] + ae);
-                lo = min(lo, b[bi] - ae);
+                const int bi = D4<B>::form[k][0], ej = D4<B>::form[k][1];
+                const uint32_t el = ej < 2 ? t4 : t6, er = ej == 0 ? n5 : ej == 1 ? t5 : ej == 2 ? n7 : t7;
+                const uint32_t bl = bi < 2 ? u0 : u1, br = bi == 0 ? nx0 : bi == 1 ? x0 : bi == 2 ? nx1 : x1;
+                uint32_t ae, mi;                            // operands are plain VALU results: no MFMA hazard for the asm
+                asm("v_sad_u32 %0, %1, %2, 0" : "=v"(ae) : "v"(el), "v"(er));
+                asm("v_sad_u32 %0, %1, %2, %3" : "=v"(mi) : "v"(bl), "v"(br), "v"(ae));
+                m = max(m, mi);
             }
         const int li = (int)__fmul_rn(tau, s32);        // tau <= 8192, s32 <= 4080: exact floor
         const bool force = (d == d0);                   // wave-uniform: the chunk's first block initialises tau
-        const bool any = force | (hi > 16 * li) | (lo < -16 * li);
+        const bool any = force | (m > 16u * (uint32_t)li);
         if (__builtin_expect(__any(any), 0)) {
             const double s64 = s64p[d];
+            const int e4 = T[4] - (int)D4_BIAS, e5 = T[5] - (int)D4_BIAS, e6 = T[6] - (int)D4_BIAS, e7 = T[7] - (int)D4_BIAS;
+            const int e[4] = {e4 + e5, e4 - e5, e6 + e7, e6 - e7};
+            const int uu0 = (int)(u0 - D4_BIAS_B), uu1 = (int)(u1 - D4_BIAS_B), xx0 = (int)(x0 - D4_BIAS_B), xx1 = (int)(x1 - D4_BIAS_B);
+            const int b[4] = {uu0 + xx0, uu0 - xx0, uu1 + xx1, uu1 - xx1};
 #pragma unroll
             for (int k = 0; k < 8; k++) {
                 const int cov = (b[D4<B>::form[k][0]] + D4<B>::form[k][2] * e[D4<B>::form[k][1]]) >> 4;   // exact: 16 | 16*cov
