@@ -238,8 +238,8 @@ def main():
         valu_per_eval = n / 4 + (15.0 / 8.0 if n_iso == 8 else 5.0)
         kernel_name = "k_sweep_fast"
         if info["sweep_kind"] == 5:
-            # k_sweep_d4: (n + n/2) / 2 v_dot2c + 54 other VALU per (range, domain), shared by the 8 copies (ISA count at B = 8)
-            valu_per_eval = ((n + n // 2) / 2 + 53.0) / 8.0
+            # k_sweep_d4: (n + n/2) / 2 v_dot2c + 37 other VALU per (range, domain), shared by the 8 copies (ISA count at B = 8)
+            valu_per_eval = ((n + n // 2) / 2 + 37.0) / 8.0
             kernel_name = "k_sweep_d4"
         valu_frac = pair_evals * valu_per_eval / 64.0 / (avg_ms * 1e-3) / VALU_WAVE_INSTR_PEAK
         traffic, traffic_note = None, None
@@ -276,7 +276,7 @@ def main():
                      "valu_instr_per_pair_eval": valu_per_eval, "peak_wave_instr_per_s": VALU_WAVE_INSTR_PEAK,
                      "note": "peak = 1 wave64 VALU instruction / 4 cycles / SIMD x 1024 SIMDs x 2.4 GHz, the measured "
                              "issue rate of v_dot4_u32_u8 and v_dot2c_i32_i16 (profiles/r01_valu_issue_rate_microbench.txt); "
-                             "k_sweep_d4's 53 non-dot instructions are mostly 2-cycle adds, so its frac is an upper estimate"
+                             "about half of k_sweep_d4's 37 non-dot instructions are 2-cycle adds, so its frac is an upper estimate; PMC: SQ_ACTIVE_INST_VALU = 93.5% of kernel cycles (profiles/r01z_cfg2_default_pmc_summary.txt)"
                              if info["sweep_kind"] == 5 else
                              "peak = 1 wave64 VALU instruction / 4 cycles / SIMD x 1024 SIMDs x 2.4 GHz, the measured "
                              "issue rate of v_dot4_u32_u8 (profiles/r01_valu_issue_rate_microbench.txt); PMC: "
