@@ -35,14 +35,6 @@ template <> struct D4<8> {
     static constexpr const int* acc = fic_d4_b8_acc;
     static constexpr const int (*form)[3] = fic_d4_b8_form;
 };
-template <> struct D4<16> {
-    static constexpr int SLOTS = FIC_D4_B16_SLOTS, TERMS = FIC_D4_B16_TERMS;
-    static constexpr const int16_t (*U)[FIC_D4_B16_TERMS][2] = fic_d4_b16_U;
-    static constexpr const int16_t (*V)[FIC_D4_B16_TERMS][2] = fic_d4_b16_V;
-    static constexpr const int* acc = fic_d4_b16_acc;
-    static constexpr const int (*form)[3] = fic_d4_b16_form;
-};
-
 // One block (n pixels in registers) -> its NW packed slot pairs.  The table is walked at compile time: every slot is a
 // signed sum of <= 8 pixels, so the whole transform is ~n*12 integer adds with constant operands.
 template <int B, bool RANGE_SIDE>

@@ -196,3 +196,33 @@ def test_mirror_generate_kernel_and_grey_image(oracle):
             L.fo_generate_kernel(Dw, Dh, idx, wK, C.byref(dy), C.byref(dx))
             out = subprocess.run([drv, "kernel", str(Dw), str(Dh), str(idx), str(wK)], capture_output=True, text=True).stdout.split()
             assert [int(v) for v in out] == [dy.value, dx.value]
+
+
+def test_d4_tables_are_verified_and_current(tmp_path):
+    """tools/gen_d4_tables.py derives the group-Fourier tables of k_sweep_d4 from the kernels' isometry definition, checks the
+    closed form against brute force on random blocks, and must reproduce the committed csrc/fic_d4_tables.h byte for byte."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("gen_d4_tables", os.path.join(root, "tools", "gen_d4_tables.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    t = gen.order_accumulators(gen.build(8))
+    packed, counts, U, V = gen.pack(t)
+    umax, vmax = gen.verify(t, packed, counts, U, V, trials=100)
+    assert len(packed) == 96 and umax < 32768 and vmax < 32768              # 48 dot2 pairs, i16 operands
+    # the isometry definition the tables are built from is the oracle's (and the kernels') iso_source
+    for k in range(8):
+        for x, y in [(0, 0), (3, 1), (7, 2), (5, 5)]:
+            assert gen.iso_source(k, 8, x, y) == oracle_iso_source(k, 8, x, y)
+    out = tmp_path / "fic_d4_tables.h"
+    gen.emit([(t, packed, counts, U, V, umax, vmax)], str(out))
+    committed = os.path.join(root, "fractal-image-compression_amd", "csrc", "fic_d4_tables.h")
+    assert out.read_text() == open(committed).read()
+
+
+def oracle_iso_source(k, B, x, y):
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import fic_oracle
+    return fic_oracle.lib().fo_iso_source(k, B, x, y)

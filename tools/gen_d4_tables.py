@@ -265,7 +265,7 @@ def emit(tables, path):
 if __name__ == "__main__":
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     tables = []
-    for B in (8, 16):
+    for B in (8,):          # B = 16 verifies too (384 slots) but its 192-dword record does not fit the SGPR file: not emitted
         t = order_accumulators(build(B))
         packed, counts, U, V = pack(t)
         umax, vmax = verify(t, packed, counts, U, V)
