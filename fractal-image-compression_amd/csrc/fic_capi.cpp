@@ -553,13 +553,7 @@ int fic_ctx_encode(fic_ctx* c, int range_begin, int range_count, void* hip_strea
     c->last_stream = s;
     if (range_count == 0) return FIC_OK;
 
-    // pool build (createCodebuch FC:119) + range prep
-    if (fic_launch_scale(c->b.gray, c->b.scaled, g, s)) return fail(FIC_E_HIP, "k_scale launch failed");
-    if (fic_launch_pool(c->b.scaled, c->b.pool_pix, c->b.pool_st, c->b.pool_var, c->b.pool_s64, g, s))
-        return fail(FIC_E_HIP, "k_pool launch failed");
-    if (fic_launch_range(c->b.gray, c->b.rng_pix, c->b.rng_st, g, s)) return fail(FIC_E_HIP, "k_range launch failed");
-
-    // sweep
+    // which sweep
     int kind = c->opt_sweep;
     if (kind == 0) {
         // full search: the VALU sweep; with 8 isometries at B = 8 its group-Fourier form (k_sweep_d4: 48 v_dot2c per pair
@@ -576,6 +570,13 @@ int fic_ctx_encode(fic_ctx* c, int range_begin, int range_count, void* hip_strea
         if (env && env[0] == '3' && env[1] == '\0' && g.full && pairs >= enough) kind = 3;
     }
     if (kind >= 2 && !g.full) return fail(FIC_E_ARGUMENT, "fast sweep needs full search (wK == Dw == Dh)");
+    if (kind == 5 && !d4_available(g)) return fail(FIC_E_ARGUMENT, "sweep 5 (k_sweep_d4) needs full search, n_iso = 8 and B = 8");
+    // pool build (createCodebuch FC:119) + range prep
+    if (fic_launch_scale(c->b.gray, c->b.scaled, g, s)) return fail(FIC_E_HIP, "k_scale launch failed");
+    if (fic_launch_pool(c->b.scaled, c->b.pool_pix, c->b.pool_st, c->b.pool_var, c->b.pool_s64, g, s))
+        return fail(FIC_E_HIP, "k_pool launch failed");
+    // k_sweep_d4 reads its own slot store and the finaliser reads the image: no isometry copies to build then
+    if (fic_launch_range(c->b.gray, c->b.rng_pix, c->b.rng_st, g, s, kind == 5 ? 0 : 1)) return fail(FIC_E_HIP, "k_range launch failed");
 
     const int tsz = 64 * g.NR;
     const int tile0 = range_begin / tsz;
@@ -586,7 +587,6 @@ int fic_ctx_encode(fic_ctx* c, int range_begin, int range_count, void* hip_strea
                              (size_t)ntiles * tsz * sizeof(unsigned long long), (size_t)g.planes, s));
     int nchunks = 1;
     int rc = FIC_OK;
-    if (kind == 5 && !d4_available(g)) return fail(FIC_E_ARGUMENT, "sweep 5 (k_sweep_d4) needs full search, n_iso = 8 and B = 8 or 16");
     if (kind == 5) rc = d4_prep(c, s);
     else if (kind >= 3) rc = matrix_core_prep(c, kind, s);              // fragment prep belongs to pool build / range prep: not timed
     if (rc == FIC_OK) rc = time_begin(c, s);
@@ -605,7 +605,7 @@ int fic_ctx_encode(fic_ctx* c, int range_begin, int range_count, void* hip_strea
     if (rc != FIC_OK) return rc;
     c->last_chunks = nchunks;
     c->last_kind = kind;
-    if (fic_launch_finalize(c->b, c->o, g, range_begin, range_count, s)) return fail(FIC_E_HIP, "k_finalize launch failed");
+    if (fic_launch_finalize(c->b, c->o, g, range_begin, range_count, s, kind == 5 ? 1 : 0)) return fail(FIC_E_HIP, "k_finalize launch failed");
     c->encoded_any = true;
     return FIC_OK;
 }

@@ -40,13 +40,14 @@ int fic_launch_argb_to_gray(const int32_t* argb, uint8_t* gray, size_t npix, hip
 int fic_launch_scale(const uint8_t* gray, uint8_t* scaled, const FicGeom& g, hipStream_t s);
 int fic_launch_pool(const uint8_t* scaled, uint8_t* pool_pix, FicDomStat* st, uint32_t* var, double* s64,
                     const FicGeom& g, hipStream_t s);
-int fic_launch_range(const uint8_t* gray, uint32_t* rng_pix, FicRngStat* rst, const FicGeom& g, hipStream_t s);
+int fic_launch_range(const uint8_t* gray, uint32_t* rng_pix, FicRngStat* rst, const FicGeom& g, hipStream_t s,
+                     int with_copies = 1);      // 0: statistics only (the sweep brings its own range store)
 int fic_launch_sweep_generic(const FicBuffers& b, const FicGeom& g, int r_begin, int r_count, hipStream_t s);
 int fic_fast_variant(int B, int n_iso, int* NR, int* NC);
 int fic_launch_sweep_fast(const FicBuffers& b, const FicGeom& g, int tile0, int ntiles, int chunk_len, int nchunks,
                           hipStream_t s);
 int fic_launch_finalize(const FicBuffers& b, const FicOutputs& out, const FicGeom& g, int r_begin, int r_count,
-                        hipStream_t s);
+                        hipStream_t s, int from_gray = 0);   // 1: recompute the winner's covariance from the image (no rng_pix)
 int fic_launch_collage(const FicBuffers& b, const FicOutputs& out, int32_t* collage, const FicGeom& g, hipStream_t s);
 int fic_launch_sqrt_probe(double* out, uint32_t first, uint32_t count, hipStream_t s);
 

@@ -195,6 +195,7 @@ __global__ __launch_bounds__(256) void k_finalize(const uint32_t* __restrict__ p
                                                   const FicDomStat* __restrict__ pool_st,
                                                   const uint32_t* __restrict__ pool_var,
                                                   const uint32_t* __restrict__ rng_pix,
+                                                  const uint8_t* __restrict__ gray,     // non-null: no isometry copies were built
                                                   const FicRngStat* __restrict__ rng_st,
                                                   const unsigned long long* __restrict__ key, FicOutputs out, FicGeom g,
                                                   int r_begin, int r_count)
@@ -212,7 +213,18 @@ __global__ __launch_bounds__(256) void k_finalize(const uint32_t* __restrict__ p
     FicDomStat ds = pool_st[(size_t)plane * g.Nd_pad + gi];
     FicRngStat rs = rng_st[(size_t)plane * g.Nr_pad + j];
     uint32_t acc = 0;
-    for (int dw = 0; dw < g.DW; dw++) acc = __builtin_amdgcn_udot4(rp[rng_word_index(g, j, k, dw)], pp[dw], acc, false);
+    if (gray) {
+        // the winner's copy straight from the image: copy_k[pos] = r[iso_source(iso_inverse(k), pos)]  (k_range_copies)
+        const uint8_t* blk = gray + (size_t)plane * g.W * g.H + (size_t)((j / g.Rw) * g.B) * g.W + (j % g.Rw) * g.B;
+        const uint8_t* pb = (const uint8_t*)pp;
+        const int ki = iso_inverse(k);
+        for (int pos = 0; pos < g.n; pos++) {
+            const int src = iso_source(ki, g.B, pos % g.B, pos / g.B);
+            acc += (uint32_t)blk[(size_t)(src / g.B) * g.W + src % g.B] * (uint32_t)pb[pos];
+        }
+    } else {
+        for (int dw = 0; dw < g.DW; dw++) acc = __builtin_amdgcn_udot4(rp[rng_word_index(g, j, k, dw)], pp[dw], acc, false);
+    }
     int dM = (int)(ds.sum >> g.lgn);
     int cov = (int)acc - rs.rM * (int)ds.sum - dM * rs.rem;
     float var = (float)pool_var[(size_t)plane * g.Nd_pad + gi];
@@ -295,20 +307,22 @@ int fic_launch_pool(const uint8_t* scaled, uint8_t* pool_pix, FicDomStat* st, ui
     return 0;
 }
 
-int fic_launch_range(const uint8_t* gray, uint32_t* rng_pix, FicRngStat* rst, const FicGeom& g, hipStream_t s)
+int fic_launch_range(const uint8_t* gray, uint32_t* rng_pix, FicRngStat* rst, const FicGeom& g, hipStream_t s, int with_copies)
 {
     hipLaunchKernelGGL(k_range_stat, dim3((g.Nr_pad + 255) / 256, g.planes), dim3(256), 0, s, gray, rst, g);
     FIC_LAUNCH_CHECK();
+    if (!with_copies) return 0;                        // k_sweep_d4 works on its own slot store (k_range_d4)
     hipLaunchKernelGGL(k_range_copies, dim3(g.tiles * g.NR, g.planes), dim3(256), 0, s, gray, rng_pix, g);
     FIC_LAUNCH_CHECK();
     return 0;
 }
 
 int fic_launch_finalize(const FicBuffers& b, const FicOutputs& out, const FicGeom& g, int r_begin, int r_count,
-                        hipStream_t s)
+                        hipStream_t s, int from_gray)
 {
     hipLaunchKernelGGL(k_finalize, dim3((r_count + 255) / 256, g.planes), dim3(256), 0, s, (const uint32_t*)b.pool_pix,
-                       b.pool_st, b.pool_var, b.rng_pix, b.rng_st, b.key, out, g, r_begin, r_count);
+                       b.pool_st, b.pool_var, b.rng_pix, from_gray ? (const uint8_t*)b.gray : (const uint8_t*)nullptr, b.rng_st,
+                       b.key, out, g, r_begin, r_count);
     FIC_LAUNCH_CHECK();
     return 0;
 }
