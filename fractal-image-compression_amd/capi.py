@@ -2,6 +2,7 @@
 there is no Python or CPU fallback for the hot path."""
 import ctypes as C
 import os
+import sys
 import re
 
 import numpy as np
@@ -35,6 +36,21 @@ def declared_symbols():
 _lib = None
 
 
+def _torch_first():
+    """PyTorch-ROCm wheels bundle their own libamdhip64 / libhsa-runtime64; libfic_hip.so uses /opt/rocm's.  Two HIP
+    runtimes share a process as long as torch's initialises first -- the other order leaves torch with "No HIP GPUs are
+    available".  So when torch is already imported, bring its runtime up before this library's first HIP call.  (A
+    process that imports torch only later should call torch.cuda.init() before its first fic call; bench.py and the
+    multi-GPU layer import torch at the top.)"""
+    t = sys.modules.get("torch")
+    if t is not None:
+        try:
+            if t.cuda.is_available():
+                t.cuda.init()
+        except Exception:       # a CPU-only box: the library itself reports FIC_E_NO_DEVICE
+            pass
+
+
 def lib():
     global _lib
     if _lib is not None:
@@ -42,6 +58,7 @@ def lib():
     if not os.path.exists(SO_PATH):
         raise FicError(-5, f"{SO_PATH} is missing: build it with __graft_entry__.build() "
                            "(hipcc --offload-arch=gfx950); there is no fallback path")
+    _torch_first()
     L = C.CDLL(SO_PATH)
     vp, ip = C.c_void_p, C.POINTER(C.c_int)
     i32p, f32p, u8p = C.POINTER(C.c_int32), C.POINTER(C.c_float), C.POINTER(C.c_uint8)
