@@ -7,22 +7,32 @@ One "step" = one pass of the hot path (pool build + range prep + sweep + finalis
 gather) over one batch of synthetic grey input that is already resident in HBM.  Default
 workload = BASELINE.json configs[1], the configuration the metric is quoted on:
 512x512 grey, 8x8 range / 16x16 domain (B=8), full search, 8 isometries -- as a batch of 64
-images per GPU so a step is milliseconds, not launch latency.  At N>1 every rank encodes its
-own batch (weak scaling: units = images, no data-path collective) and the codebooks are
-gathered to rank 0 with one RCCL gather per step (the path's only exchange).
+images per GPU so a step is milliseconds, not launch latency (the literal single image is timed
+too and reported as `single_image`).  At N>1 every rank encodes its own batch (weak scaling:
+units = images, no data-path collective) and the codebooks are gathered to rank 0 with one RCCL
+gather per step (the path's only exchange), overlapped with the next step's sweep.
 `--workload cfg4 --scaling strong` shards ONE 4096x4096 image's range blocks across the ranks.
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant
-kernel = the pool sweep; algorithmic bytes = ranges x N_d x (n+8) per launch) and
-`cpu_baseline` (the C oracle, 1 core, bounded sample).
+Launch: `python bench.py --gpus N` from a bare shell starts its own N rank processes (fresh
+children, spawned before this process touches torch or the GPU; it waits for them and exits
+with their worst code); under `python -m torch.distributed.run ... bench.py --gpus N` the
+RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* environment is used as given.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (the compute
+bound of the sweep kernel that ran: matrix-core FLOP/s against the dense MFMA peak, or VALU
+issue for the VALU-only sweeps), `roofline_hbm_logical` (SURVEY 8d's byte model, which the
+sweep exceeds by the register-tile reuse factor), `valu_only` (the same workload through the
+VALU-only sweep north_star describes), `single_image` and `cpu_baseline` (the C oracle, 1 core,
+bounded sample).
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -46,12 +56,89 @@ WORKLOADS = {
 }
 
 HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "i8": 5000.0}   # dense peaks, MI355X_MICROARCH.md "Matrix cores"
 # Measured on MI355X (profiles/r01_valu_issue_rate_microbench.txt): v_dot4_u32_u8 -- like v_mad_i32_i24,
 # v_cvt_*, v_cmp_* and any VALU op with an SGPR source -- issues one wave64 instruction per 4 cycles
-# per SIMD (only plain v_fma_f32 / v_add_u32 reach 2 cycles).  Peak for this kernel's instruction mix:
+# per SIMD (only plain v_fma_f32 / v_add_u32 reach 2 cycles).  Peak for the VALU sweeps' instruction mix:
 VALU_WAVE_INSTR_PEAK = 256 * 4 * 2.4e9 / 4.0   # wave-instructions/s, chip-wide, at the 2.4 GHz max clock
 
+# sweep kind (fic_ctx_info) -> (kernel family, operand type or None)
+SWEEP_KINDS = {1: ("k_sweep_generic", None), 2: ("k_sweep_fast", None), 5: ("k_sweep_d4", None),
+               3: ("matrix-core (exact covariances)", "bf16"), 4: ("matrix-core (i8 operands)", "i8"),
+               6: ("matrix-core (normalised f16 prune GEMM)", "f16")}
 
+
+def csrc_hash():
+    """Identity of the kernel sources: profiles/traffic.json entries are only trusted for the tree they were measured on."""
+    d = os.path.join(ROOT, "fractal-image-compression_amd", "csrc")
+    h = hashlib.sha256()
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h", ".cpp")):
+            h.update(name.encode())
+            h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()[:12]
+
+
+def kernel_name(kind, B, n_iso):
+    if kind == 3:
+        bf16 = B <= 8 or n_iso == 8
+        return ("k_sweep_bf16" if bf16 else "k_sweep_mfma") + ("" if n_iso == 8 else ("_1" if bf16 else "1")), ("bf16" if bf16 else "i8")
+    if kind == 4:
+        return "k_sweep_mfma" + ("" if n_iso == 8 else "1"), "i8"
+    if kind == 6:
+        return ("k_sweep_q8" if n_iso == 8 else "k_sweep_q1"), "f16"
+    return SWEEP_KINDS.get(kind, ("k_sweep_fast", None))[0], None
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# self-launch: `python bench.py --gpus N` from a bare shell
+# ----------------------------------------------------------------------------------------------------------------
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_ranks(n, cmd, env=None, poll_s=0.2):
+    """Starts `cmd` n times as fresh child processes with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT
+    set (one process per GPU; rendezvous on 127.0.0.1), waits for all of them and returns the worst exit code.  If a
+    rank fails, the others are stopped (their exact PIDs) instead of being left at a barrier.  The calling process
+    must not have touched the GPU: nothing here imports torch or loads libfic_hip.so."""
+    base = dict(os.environ if env is None else env)
+    base.update(WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    procs = []
+    for r in range(n):
+        e = dict(base, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen(cmd, env=e))
+    worst = 0
+    live = set(range(n))
+    while live:
+        for r in sorted(live):
+            rc = procs[r].poll()
+            if rc is None:
+                continue
+            live.discard(r)
+            if rc != 0:
+                worst = worst or (rc if rc > 0 else 128 - rc)
+                for o in sorted(live):            # a failed rank leaves the others waiting at a collective
+                    procs[o].terminate()
+        if live:
+            time.sleep(poll_s)
+            if worst:
+                deadline = time.time() + 10.0
+                while live and time.time() < deadline:
+                    live = {r for r in live if procs[r].poll() is None}
+                    time.sleep(poll_s)
+                for o in sorted(live):
+                    procs[o].kill()
+                    procs[o].wait()
+                live = set()
+    return worst
+
+
+# ----------------------------------------------------------------------------------------------------------------
 def cpu_baseline(wl, img, budget_s=12.0):
     """The oracle (C restatement of the Java loops, -O2, 1 thread) on a bounded sample of the
     same workload: the first ranges of image 0 against its full pool."""
@@ -91,7 +178,33 @@ def cpu_baseline(wl, img, budget_s=12.0):
     return out
 
 
-def main():
+def probe(args, world, rank):
+    """--probe: the launcher + rendezvous + codebook gather with synthetic records on the CPU (gloo), no GPU and no
+    libfic_hip.so.  Used by tests/test_bench_launcher.py; its output is not a benchmark line."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import fic_amd
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    spans = fic_amd.shard_spans(1000, 64, world)
+    b, c = spans[rank]
+    rec = torch.from_numpy(np.arange(b * 6, (b + c) * 6, dtype=np.int32).reshape(1, c, 6))
+    full = fic_amd.gather_records(rec, spans, None, 0) if world > 1 else rec
+    ok = None
+    if rank == 0:
+        ok = bool((full.numpy().reshape(-1) == np.arange(6000, dtype=np.int32)).all())
+        print(json.dumps({"probe": True, "n_gpus": world, "gather_ok": ok, "spans": spans,
+                          "rank_env": {k: os.environ.get(k) for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR")}}))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if args.probe_fail_rank is not None and rank == args.probe_fail_rank:
+        sys.exit(7)
+    return 0 if (ok or rank != 0) else 1
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -106,14 +219,32 @@ def main():
                     help="synthetic input: U = iid bytes (the quoted distribution), S = flat tiles + noise, "
                          "lena = LenaGrey.png tiled/cropped to size with a per-image shift (robustness checks)")
     ap.add_argument("--chunks", type=int, default=0)
-    ap.add_argument("--sweep", type=int, default=0, choices=[0, 2, 3, 4, 5],
-                    help="0/2 = VALU sweep k_sweep_fast (default, north_star's design); 3 = opt-in matrix-core sweep "
-                         "(bf16 operands; i8 at B = 16 with 1 isometry); 4 = matrix-core sweep with i8 operands at every B")
+    ap.add_argument("--sweep", type=int, default=0, choices=[0, 2, 3, 4, 5, 6],
+                    help="0 = library default (matrix-core sweep for full search); 2 / 5 = VALU-only sweeps (k_sweep_fast / "
+                         "k_sweep_d4, north_star's literal design); 3 / 4 = matrix-core sweeps with exact covariances "
+                         "(bf16 / i8 operands); 6 = matrix-core sweep with the normalised f16 prune GEMM")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-alt", action="store_true", help="skip the extra timing of the opt-in matrix-core sweep")
+    ap.add_argument("--no-alt", action="store_true", help="skip the extra timings (valu_only, single_image)")
     ap.add_argument("--cpu-budget", type=float, default=12.0)
-    args = ap.parse_args()
+    ap.add_argument("--inproc", action="store_true",
+                    help="time the in-library multi-device entry fic_encode_gray_u8_multi (one process, --gpus devices) instead")
+    ap.add_argument("--probe", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--probe-fail-rank", type=int, default=None, help=argparse.SUPPRESS)
+    return ap.parse_args(argv)
 
+
+def main():
+    args = parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1 and not args.inproc:
+        # bare `python bench.py --gpus N`: become the launcher.  Nothing GPU-related has been imported yet.
+        sys.exit(launch_ranks(args.gpus, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.probe:
+        sys.exit(probe(args, world, rank))
+
+    import numpy as np
     import torch
     import fic_amd
 
@@ -127,19 +258,19 @@ def main():
     if args.n_iso:
         wl["n_iso"] = args.n_iso
     scaling = args.scaling or wl["scaling"]
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one process per GPU)")
+    if not args.inproc:
         args.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: the hot path has no CPU fallback")
+    if args.inproc:
+        sys.exit(bench_inproc(args, wl))
     # FIC_BENCH_BACKEND=gloo is a rehearsal mode for boxes with fewer GPUs than ranks (ranks share devices,
     # records travel through host memory); the real multi-GPU run uses nccl == RCCL over xGMI.
     backend = os.environ.get("FIC_BENCH_BACKEND", "nccl")
     local_rank = local_rank % torch.cuda.device_count() if backend == "gloo" else local_rank
+    if local_rank >= torch.cuda.device_count():
+        sys.exit(f"rank {rank}: LOCAL_RANK {local_rank} but only {torch.cuda.device_count()} GPU(s) visible "
+                 f"(FIC_BENCH_BACKEND=gloo rehearses more ranks than GPUs)")
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
@@ -150,18 +281,25 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
+    def barrier():
+        if dist:
+            if backend == "nccl":
+                dist.barrier(device_ids=[local_rank])
+            else:
+                dist.barrier()
+
     W, H, B, n_iso, planes = wl["W"], wl["H"], wl["B"], wl["n_iso"], wl["planes"]
     seed = fic_amd.synth.SEEDS[wl["seed"]]
     # synthetic input, generated once and uploaded: resident in HBM before any timing
-    def make_image(s):
+    def make_image(s, w=W, h=H):
         if args.dist == "U":
-            return fic_amd.synth.image_u(W, H, s)
+            return fic_amd.synth.image_u(w, h, s)
         if args.dist == "S":
-            return fic_amd.synth.image_s(W, H, s)
+            return fic_amd.synth.image_s(w, h, s)
         base = np.load(os.path.join(ROOT, "tests", "golden", "lena_grey_256.npy"))
-        t = np.tile(base, ((H + 511) // 256 + 1, (W + 511) // 256 + 1))
+        t = np.tile(base, ((h + 511) // 256 + 1, (w + 511) // 256 + 1))
         oy, ox = (s * 7) % 256, (s * 13) % 256
-        return np.ascontiguousarray(t[oy:oy + H, ox:ox + W])
+        return np.ascontiguousarray(t[oy:oy + h, ox:ox + w])
 
     if scaling == "weak":
         imgs = np.stack([make_image(seed + 3 * (rank * planes + p)) for p in range(planes)])
@@ -172,169 +310,242 @@ def main():
     if scaling == "strong":
         enc = fic_amd.ShardedEncoder(W, H, B, None, n_iso, planes, local_rank)
         core = enc.enc
-        begin, count = enc.spans[rank]
+        spans = enc.spans
     else:
         core = fic_amd.Encoder(W, H, B, None, n_iso, planes, local_rank)
-        begin, count = 0, core.n_ranges
         spans = [(0, core.n_ranges)] * world
+    begin, count = spans[rank]
     core.set_gray(dev_in)
     core.set_option("time_sweep", 1)
     if args.chunks:
         core.set_option("chunks", args.chunks)
     if args.sweep:
         core.set_option("sweep", args.sweep)
-    stream = torch.cuda.current_stream()
-    res_dev = core.results_device()
+    # The sweep runs on a compute stream of its own; the codebook gather of step k runs on torch's current stream
+    # (where the nccl backend orders its collectives) and overlaps with the sweep of step k+1.
+    compute = torch.cuda.Stream()
+    records = core.records_device()                       # [planes, N_r, 6] int32, written by every encode
+    stage = [None, None]                                  # double-buffered copies of this rank's span
+    staged = [None, None]
+    gathered = [None, None]
+    step_no = [0]
 
     def step():
-        core.encode(begin, count, stream)
-        if world > 1:
-            rec = fic_amd.pack_records(res_dev, begin, count)
-            if backend != "nccl":
-                rec = rec.cpu()
-            if scaling == "strong":
-                fic_amd.gather_records(rec, enc.spans, None, 0)
-            else:
-                fic_amd.gather_records(rec, spans, None, 0)
+        k = step_no[0] & 1
+        step_no[0] += 1
+        if world == 1:
+            core.encode(begin, count, compute)
+            return
+        with torch.cuda.stream(compute):
+            if gathered[k] is not None:
+                compute.wait_event(gathered[k])           # the gather that last read stage[k] has finished
+            core.encode(begin, count, compute)
+            stage[k] = records[:, begin:begin + count].contiguous() if stage[k] is None else stage[k].copy_(records[:, begin:begin + count])
+            staged[k] = torch.cuda.Event()
+            staged[k].record(compute)
+        cur = torch.cuda.current_stream()
+        cur.wait_event(staged[k])
+        rec = stage[k] if backend == "nccl" else stage[k].cpu()
+        fic_amd.gather_records(rec, spans, None, 0)
+        gathered[k] = torch.cuda.Event()
+        gathered[k].record(cur)
+
+    def timed(nsteps):
+        torch.cuda.synchronize()
+        core.sweep_time(reset=True)
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(nsteps):
+            step()
+        torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        ms, n = core.sweep_time(reset=True)
+        return dt, ms, n
 
     for _ in range(args.warmup):
         step()
-    torch.cuda.synchronize()
-    core.sweep_time(reset=True)
+    dt, sweep_ms, sweep_n = timed(args.steps)
+    per_rank_sweep_ms = [sweep_ms / max(sweep_n, 1)]
+    rccl_ranks = None
     if dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    sweep_ms, sweep_n = core.sweep_time(reset=True)
-    if dist:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        dev = "cuda" if backend == "nccl" else "cpu"
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        mine = torch.tensor([sweep_ms / max(sweep_n, 1)], dtype=torch.float64, device=dev)
+        allms = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allms, mine)
+        per_rank_sweep_ms = [float(x.item()) for x in allms]
+        rccl_ranks = dist.get_world_size() if backend == "nccl" else 0
 
     Nr, Nd, n = core.n_ranges, core.n_domains, B * B
     ranges_per_step_rank = count * planes
-    if scaling == "weak":
-        total_ranges = Nr * planes * world * args.steps
-    else:
-        total_ranges = Nr * planes * args.steps
+    total_ranges = Nr * planes * (world if scaling == "weak" else 1) * args.steps
     value = total_ranges / dt
     info = core.info()
 
     if rank == 0:
+        kind = info["sweep_kind"]
+        kname, operand = kernel_name(kind, B, n_iso)
         avg_ms = sweep_ms / max(sweep_n, 1)
-        alg_bytes = float(ranges_per_step_rank) * Nd * (n + 8)      # n+8 bytes per (range,domain) pair
-        achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
         pair_evals = float(ranges_per_step_rank) * Nd * n_iso
-        # VALU instructions per pair evaluation of the sweep kernel (static count from the ISA):
-        # n/4 v_dot4 per pair evaluation, plus per (range, domain): 1 iso -> 2 (base) + mul + cvt + cmp = 5;
-        # 8 iso -> 2 (base) + mul + cvt + 8 (max3/min3 reduction of the 8 copies) + sub + 2 cmp = 15, shared by 8
-        valu_per_eval = n / 4 + (15.0 / 8.0 if n_iso == 8 else 5.0)
-        kernel_name = "k_sweep_fast"
-        if info["sweep_kind"] == 5:
-            # k_sweep_d4: (n + n/2) / 2 v_dot2c + 37 other VALU per (range, domain), shared by the 8 copies (ISA count at B = 8)
-            valu_per_eval = ((n + n // 2) / 2 + 37.0) / 8.0
-            kernel_name = "k_sweep_d4"
-        valu_frac = pair_evals * valu_per_eval / 64.0 / (avg_ms * 1e-3) / VALU_WAVE_INSTR_PEAK
-        traffic, traffic_note = None, None
-        try:   # HBM-side bytes per sweep launch from the committed rocprofv3 PMC passes (profiles/traffic.json)
+        # SURVEY 8(d)'s byte model: n+8 bytes per (range, domain) pair, one pool read per range block
+        alg_bytes = float(ranges_per_step_rank) * Nd * (n + 8)
+        hbm_logical = {"bound": "hbm (logical)", "achieved": alg_bytes / (avg_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                       "frac": alg_bytes / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": alg_bytes,
+                       "ranges_per_pool_read": 64 if operand is None else 16,
+                       "note": "SURVEY 8(d): ranges x N_d x (n+8) bytes per launch.  NOT the bound of this kernel: a wave keeps its "
+                               "range tile in registers and reads a pool block once for all of it (`ranges_per_pool_read` per wave, "
+                               "four waves of a workgroup share the load through L1), so the physical traffic is `traffic` and the "
+                               "sweep is compute-bound (roofline)"}
+        traffic, traffic_note = None, "no PMC pass recorded for this kernel/workload on this source tree (tools/gpu_traffic.sh writes profiles/traffic.json)"
+        try:   # HBM-side bytes per sweep launch from a rocprofv3 --pmc side pass of this same command (profiles/traffic.json)
             tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-            ent = tj.get(f"{args.workload}:planes={planes}:n_iso={n_iso}:sweep={info['sweep_kind']}:gpus={world}")
-            if ent:
+            ent = tj.get(f"{args.workload}:planes={planes}:n_iso={n_iso}:kernel={kname}:gpus={world}")
+            if ent and ent.get("csrc_hash") == csrc_hash():
                 traffic, traffic_note = ent["bytes_per_launch"], ent["how"]
+            elif ent:
+                traffic_note = f"stale: profiles/traffic.json was measured on csrc {ent.get('csrc_hash')}, this tree is {csrc_hash()}"
         except (OSError, ValueError, KeyError):
             pass
+        if operand is not None:
+            # matrix-core sweeps: algorithmic work = 2n flop per pair evaluation (n MACs per pair)
+            peak = MFMA_PEAK_TFLOPS[operand]
+            ops = pair_evals * 2.0 * n
+            roofline = {"bound": "mfma", "achieved": ops / (avg_ms * 1e-3) / 1e12, "peak": peak,
+                        "unit": "TFLOP/s" if operand != "i8" else "TOP/s", "frac": ops / (avg_ms * 1e-3) / 1e12 / peak,
+                        "traffic": traffic, "traffic_note": traffic_note, "kernel": kname, "operands": operand,
+                        "avg_launch_ms": avg_ms, "launches": sweep_n, "algorithmic_flop_per_launch": ops,
+                        "note": "algorithmic flop = range blocks x N_d x n_iso x 2n per launch; duration from HIP events on the "
+                                "sweep's stream inside the timed region"}
+        else:
+            # VALU instructions per pair evaluation of the sweep kernel (static count from the ISA):
+            # k_sweep_fast: n/4 v_dot4 per pair evaluation, plus per (range, domain): 1 iso -> 5; 8 iso -> 15, shared by 8
+            # k_sweep_d4: (n + n/2) / 2 v_dot2c + 37 other VALU per (range, domain), shared by the 8 copies (ISA count at B = 8)
+            vpe = ((n + n // 2) / 2 + 37.0) / 8.0 if kind == 5 else n / 4 + (15.0 / 8.0 if n_iso == 8 else 5.0)
+            ach = pair_evals * vpe / 64.0 / (avg_ms * 1e-3)
+            roofline = {"bound": "valu", "achieved": ach / 1e9, "peak": VALU_WAVE_INSTR_PEAK / 1e9, "unit": "G wave-instr/s",
+                        "frac": ach / VALU_WAVE_INSTR_PEAK, "traffic": traffic, "traffic_note": traffic_note, "kernel": kname,
+                        "avg_launch_ms": avg_ms, "launches": sweep_n, "valu_instr_per_pair_eval": vpe,
+                        "note": "peak = 1 wave64 VALU instruction / 4 cycles / SIMD x 1024 SIMDs x 2.4 GHz, the measured issue rate "
+                                "of v_dot4_u32_u8 / v_dot2c_i32_i16 (profiles/r01_valu_issue_rate_microbench.txt)"}
         out = {
             "metric": "range-block matches/sec (8x8 R, 16x16 D, 8 iso)" if (B == 8 and n_iso == 8) else
                       f"range-block matches/sec ({B}x{B} R, {2 * B}x{2 * B} D, {n_iso} iso)",
             "value": value, "unit": "range-block matches/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": scaling, "vs_baseline": None, "dtype": "u8",
-            "dtype_detail": ("u8 pixels -> i16 group-Fourier slots of the 8 isometries, v_dot2c_i32_i16 -> exact i32 covariances, "
-                             "f32 prune test, f64/f32 Java epilogue") if info["sweep_kind"] == 5 else
-                            "u8 pixels, v_dot4_u32_u8 -> exact i32 covariances, f32 prune test, f64/f32 Java epilogue",
+            "dtype_detail": {"bf16": "centred u8 pixels as exact bf16, v_mfma_f32_32x32x16_bf16 -> exact f32 covariances, f32 prune test, f64/f32 Java epilogue",
+                             "i8": "u8 pixels shifted to i8, v_mfma_i32_32x32x32_i8 -> exact i32 covariances, same epilogue",
+                             "f16": "centred u8 range pixels (exact f16) x normalised domain pixels (f16), v_mfma_f32_32x32x16_f16 -> "
+                                    "|cov|/sqrt(var) within a proven bound = the prune test; surviving pairs: exact integer covariance "
+                                    "(v_dot4_u32_u8) + f64/f32 Java epilogue",
+                             None: "u8 pixels, v_dot4_u32_u8 / v_dot2c_i32_i16 -> exact i32 covariances, f32 prune test, f64/f32 Java epilogue"}[operand],
             "data": "synthetic",
             "config": {"workload": wl["desc"] if args.dist == "U" else wl["desc"].replace("synthetic grey U", f"grey {args.dist}"),
                        "dist": args.dist, "image": f"{W}x{H}", "B": B, "n_iso": n_iso, "wK": core.wK,
                        "planes_per_rank" if scaling == "weak" else "planes": planes,
-                       "N_r": Nr, "N_d": Nd, "pool_chunks": info["chunks"], "parallelism": f"range/plane shards x{world}"},
+                       "N_r": Nr, "N_d": Nd, "pool_chunks": info["chunks"], "sweep_kind": kind,
+                       "parallelism": f"range/plane shards x{world}"},
             "pair_evals_per_s": pair_evals * sweep_n / (sweep_ms * 1e-3) if sweep_ms > 0 else None,
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,
-                         "kernel": kernel_name, "avg_launch_ms": avg_ms, "launches": sweep_n,
-                         "algorithmic_bytes_per_launch": alg_bytes,
-                         "note": "algorithmic bytes = ranges x N_d x (n+8); each wave keeps 64 range blocks in VGPRs "
-                                 "and reads a pool block once for all of them, so frac > 1 means the sweep is past the "
-                                 "HBM roofline and bounded by VALU issue instead (see valu)"},
-            "valu": {"bound": "valu-issue (the true bound of this kernel)", "frac": valu_frac,
-                     "valu_instr_per_pair_eval": valu_per_eval, "peak_wave_instr_per_s": VALU_WAVE_INSTR_PEAK,
-                     "note": "peak = 1 wave64 VALU instruction / 4 cycles / SIMD x 1024 SIMDs x 2.4 GHz, the measured "
-                             "issue rate of v_dot4_u32_u8 and v_dot2c_i32_i16 (profiles/r01_valu_issue_rate_microbench.txt); "
-                             "about half of k_sweep_d4's 37 non-dot instructions are 2-cycle adds, so its frac is an upper estimate; PMC: SQ_ACTIVE_INST_VALU = 93.5% of kernel cycles (profiles/r01z_cfg2_default_pmc_summary.txt)"
-                             if info["sweep_kind"] == 5 else
-                             "peak = 1 wave64 VALU instruction / 4 cycles / SIMD x 1024 SIMDs x 2.4 GHz, the measured "
-                             "issue rate of v_dot4_u32_u8 (profiles/r01_valu_issue_rate_microbench.txt); PMC: "
-                             "SQ_ACTIVE_INST_VALU = 96% of kernel cycles (profiles/r01a_cfg2_pmc_summary.txt)"},
+            "roofline": roofline,
+            "roofline_hbm_logical": hbm_logical,
+            "rccl_ranks": rccl_ranks,
+            "per_rank_sweep_ms": per_rank_sweep_ms,
+            "csrc_hash": csrc_hash(),
         }
-        if info["sweep_kind"] in (3, 4):
-            # opt-in matrix-core sweeps.  "sweep" = 3 at B = 4/8 (and B = 16 with 8 isometries): centred pixels as exact bf16 operands of
-            # v_mfma_f32_32x32x16_bf16 (dense bf16 peak 2.5 PFLOP/s); otherwise u8 shifted to i8 on
-            # v_mfma_i32_32x32x32_i8 (dense i8 peak 5.0 PetaOP/s) -- MI355X_MICROARCH.md "Matrix cores".
-            bf16 = info["sweep_kind"] == 3 and (B <= 8 or n_iso == 8)
-            kname = ("k_sweep_bf16" if bf16 else "k_sweep_mfma") + ("" if n_iso == 8 else ("_1" if bf16 else "1"))
-            peak = 2500.0 if bf16 else 5000.0
-            ops = pair_evals * 2.0 * n
-            out["dtype_detail"] = ("centred u8 pixels as exact bf16, v_mfma_f32_32x32x16_bf16 -> exact f32 covariances, same epilogue"
-                                   if bf16 else
-                                   "u8 pixels shifted to i8, v_mfma_i32_32x32x32_i8 -> exact i32 covariances, same epilogue")
-            out["roofline_hbm_logical"] = dict(out["roofline"], kernel=kname)
-            out["roofline"] = {"bound": "mfma", "achieved": ops / (avg_ms * 1e-3) / 1e12, "peak": peak,
-                               "unit": "TFLOP/s" if bf16 else "TOP/s", "frac": ops / (avg_ms * 1e-3) / 1e12 / peak,
-                               "traffic": None, "kernel": kname, "avg_launch_ms": avg_ms, "launches": sweep_n,
-                               "note": "opt-in (--sweep 3/4): north_star rules MFMA out for this path; default is the VALU sweep"}
-            # bf16 kernels: 28 (8 iso) / 27 (1 iso) VALU wave-instructions per 32x32 tile of pair evaluations (ISA count)
-            vpe = (28.0 * 64 / 1024 if n_iso == 8 else 27.0 * 64 / 1024) if bf16 else (3.5 if n_iso == 8 else 6.0)
-            out["valu"] = {"bound": "valu-issue (epilogue)", "valu_instr_per_pair_eval": vpe,
-                           "frac": pair_evals * vpe / 64.0 / (avg_ms * 1e-3) / VALU_WAVE_INSTR_PEAK,
-                           "peak_wave_instr_per_s": VALU_WAVE_INSTR_PEAK}
-        if info["sweep_kind"] in (2, 5) and world == 1 and not args.no_alt:
-            # Same workload, same buffers, through the opt-in matrix-core sweep: reported beside, never as `value`.
-            core.set_option("sweep", 3)
+        if world == 1 and not args.no_alt and operand is not None:
+            # north_star's literal design (VALU only, no MFMA) on the same workload and buffers: reported beside, never as `value`
+            core.set_option("sweep", 5 if (B == 8 and n_iso == 8) else 2)
             for _ in range(args.warmup):
                 step()
-            torch.cuda.synchronize()
-            core.sweep_time(reset=True)
-            t1 = time.perf_counter()
-            for _ in range(args.steps):
-                step()
-            torch.cuda.synchronize()
-            dt3 = time.perf_counter() - t1
-            ms3, n3 = core.sweep_time(reset=True)
+            dtv, msv, nv = timed(args.steps)
+            iv = core.info()
             core.set_option("sweep", args.sweep)
-            out["opt_in_matrix_core"] = {
-                "how": "bench.py --sweep 3 / fic_ctx_set_option(ctx, \"sweep\", 3)",
-                "kernel": (("k_sweep_bf16" if n_iso == 8 else "k_sweep_bf16_1") if (B <= 8 or n_iso == 8) else "k_sweep_mfma1"),
-                "value": total_ranges / dt3, "unit": "range-block matches/s", "ms_per_step": dt3 / args.steps * 1e3,
-                "avg_launch_ms": ms3 / max(n3, 1), "speedup_vs_default": dt / dt3,
-                "mfma_roofline_frac": (pair_evals * 2.0 * n) / (ms3 / max(n3, 1) * 1e-3) / 1e12 /
-                                      (2500.0 if (B <= 8 or n_iso == 8) else 5000.0),
-                "note": "bit-identical codebooks (tests/test_gpu_mfma.py); inner products on v_mfma_f32_32x32x16_bf16 "
-                        "(centred pixels are exact bf16) or, at B = 16 with 1 isometry, v_mfma_i32_32x32x32_i8. "
-                        "Not the default because north_star asks for a VALU-only sweep (DESIGN.md section 6)."}
+            out["valu_only"] = {"how": "fic_ctx_set_option(ctx, \"sweep\", 5 or 2) / FIC_SWEEP=5", "kernel": kernel_name(iv["sweep_kind"], B, n_iso)[0],
+                                "value": total_ranges / dtv, "unit": "range-block matches/s", "ms_per_step": dtv / args.steps * 1e3,
+                                "avg_launch_ms": msv / max(nv, 1), "default_speedup": dtv / dt,
+                                "note": "bit-identical codebooks (tests/test_gpu_mfma.py, test_gpu_fullsize.py); this is the sweep "
+                                        "north_star describes (no MFMA).  Its premise -- reduction/bandwidth-bound -- does not hold: "
+                                        "profiles/r01z_cfg2_default_pmc_summary.txt shows 0.7 % of HBM peak and VALU busy 93.5 %, so the "
+                                        "library default is the matrix-core sweep"}
+        if world == 1 and not args.no_alt and args.workload == "cfg2" and not (args.size or args.block or args.planes or args.n_iso):
+            out["single_image"] = single_image(fic_amd, torch, make_image(seed), B, n_iso, local_rank, args.sweep)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(wl, imgs[0], args.cpu_budget)
         else:
             out["cpu_baseline"] = None
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
+    barrier()
     if dist:
-        dist.barrier()
         dist.destroy_process_group()
+
+
+def single_image(fic_amd, torch, img, B, n_iso, device, sweep, reps=200):
+    """The literal BASELINE config 2: ONE 512x512 image, resident in HBM.  `ms` = back-to-back encodes on one stream
+    (what a caller streaming images sees); `latency_ms` = one encode + stream sync, host clock."""
+    H, W = img.shape
+    enc = fic_amd.Encoder(W, H, B, None, n_iso, 1, device)
+    d = torch.from_numpy(img[None]).cuda()
+    enc.set_gray(d)
+    if sweep:
+        enc.set_option("sweep", sweep)
+    s = torch.cuda.Stream()
+    for _ in range(5):
+        enc.encode(0, -1, s)
+    s.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(s)
+    for _ in range(reps):
+        enc.encode(0, -1, s)
+    e1.record(s)
+    s.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    lat = []
+    for _ in range(50):
+        t0 = time.perf_counter()
+        enc.encode(0, -1, s)
+        s.synchronize()
+        lat.append((time.perf_counter() - t0) * 1e3)
+    lat.sort()
+    enc.set_option("time_sweep", 1)
+    for _ in range(20):
+        enc.encode(0, -1, s)
+    sw_ms, sw_n = enc.sweep_time(reset=True)
+    info = enc.info()
+    nr = enc.n_ranges
+    enc.close()
+    return {"workload": f"one {W}x{H} synthetic grey U image, B={B}, full search, {n_iso} iso (BASELINE config 2 literally)",
+            "ms": ms, "matches_per_s": nr / (ms * 1e-3), "latency_ms": lat[len(lat) // 2],
+            "sweep_ms": sw_ms / max(sw_n, 1), "kernel": kernel_name(info["sweep_kind"], B, n_iso)[0], "pool_chunks": info["chunks"],
+            "note": "ms: HIP events around 200 back-to-back encodes (pool build + range prep + sweep + finalise each); "
+                    "latency_ms: median host time of encode + sync"}
+
+
+def bench_inproc(args, wl):
+    """--inproc: the in-library multi-device entry (one process, one host thread, args.gpus devices, RCCL gather
+    inside the library) -- what the JNI host calls.  Host buffers in and out, so this figure includes PCIe."""
+    import numpy as np
+    import fic_amd
+    from fic_amd import capi
+    W, H, B, n_iso = wl["W"], wl["H"], wl["B"], wl["n_iso"]
+    img = fic_amd.synth.image_u(W, H, fic_amd.synth.SEEDS[wl["seed"]])
+    for _ in range(max(args.warmup, 1)):
+        capi.encode_gray_multi(img, B, None, n_iso, args.gpus)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        r = capi.encode_gray_multi(img, B, None, n_iso, args.gpus)
+    dt = time.perf_counter() - t0
+    nr = r["idx_local"].size
+    print(json.dumps({"metric": f"range-block matches/sec ({B}x{B} R, {2 * B}x{2 * B} D, {n_iso} iso), in-library multi-device entry",
+                      "value": nr * args.steps / dt, "unit": "range-block matches/s", "n_gpus": args.gpus, "steps": args.steps,
+                      "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
+                      "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+                      "config": {"workload": wl["desc"] + " -- fic_encode_gray_u8_multi, host buffers in/out (PCIe inclusive)"}}))
+    return 0
 
 
 if __name__ == "__main__":

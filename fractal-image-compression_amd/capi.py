@@ -81,6 +81,7 @@ def lib():
         "fic_ctx_sync": (C.c_int, [vp]),
         "fic_ctx_get_results_host": (C.c_int, [vp, i32p, f32p, f32p, i32p, i32p, i32p, f32p]),
         "fic_ctx_result_device_ptrs": (C.c_int, [vp] + [C.POINTER(vp)] * 7),
+        "fic_ctx_records_device_ptr": (C.c_int, [vp, C.POINTER(vp)]),
         "fic_ctx_collage_host": (C.c_int, [vp, i32p]),
         "fic_encode_rgb_argb": (C.c_int, [i32p] + [C.c_int] * 5 + [i32p, f32p, f32p, f32p, f32p, i32p, i32p]),
         "fic_write_run_rgb": (C.c_int64, [i32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, u8p, C.c_int64]),

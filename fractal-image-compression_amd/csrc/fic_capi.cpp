@@ -128,7 +128,7 @@ int ctx_free_all(fic_ctx* c)
     c->ev.clear();
     void* ptrs[] = {c->gray_own, c->argb_stage, c->collage, c->decoded, c->mfma_poolB, c->mfma_rngA, c->mfma_sw, c->mfma_rconst, c->d4_rng, c->d4_pool, c->b.scaled, c->b.pool_pix, c->b.pool_st, c->b.pool_var,
                     c->b.pool_s64, c->b.rng_pix, c->b.rng_st, c->b.key, c->o.idx_local, c->o.idx_global, c->o.iso,
-                    c->o.a, c->o.b, c->o.err, c->o.qrows};
+                    c->o.a, c->o.b, c->o.err, c->o.qrows, c->o.records};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     return FIC_OK;
@@ -195,6 +195,10 @@ void cache_give(fic_ctx* c)
 int time_begin(fic_ctx* c, hipStream_t s)
 {
     if (!c->opt_time) return FIC_OK;
+    if (c->ev.size() >= 256) {                     // bound the pending list: fold finished launches into the accumulators
+        int rc = flush_events(c);
+        if (rc) return rc;
+    }
     hipEvent_t e0 = nullptr;
     HIP_TRY(hipEventCreate(&e0));
     c->ev.push_back(e0);
@@ -211,18 +215,15 @@ int time_end(fic_ctx* c, hipStream_t s)
     return FIC_OK;
 }
 
-// Default VALU sweep (k_sweep_fast) over tiles [tile0, tile0 + ntiles).
-int valu_sweep(fic_ctx* c, int tile0, int ntiles, hipStream_t s, int* nchunks_out)
+// Pool chunks per range tile for the VALU sweeps (k_sweep_fast, k_sweep_d4).  Measured (profiles/r01l_chunk_sweep.txt):
+// every chunk pays a start-up (its first block is evaluated exactly and tau restarts), so chunks stay >= 4096 blocks
+// while aiming at ~48 K wave tasks for load balance; only a launch that could not otherwise fill the chip (one small
+// image) splits finer.  `base_waves` = wave tasks per chunk.
+int valu_chunk_count(const fic_ctx* c, long long base_waves)
 {
     const FicGeom& g = c->g;
-    int NR, NC;
-    fic_fast_variant(g.B, g.n_iso, &NR, &NC);
-    const long long base_waves = (long long)ntiles * (g.n_iso / NC) * g.planes;
     int nchunks = c->opt_chunks;
     if (nchunks <= 0) {
-        // Measured (profiles/r01l_chunk_sweep.txt): every chunk pays a start-up (its first block is evaluated
-        // exactly and tau restarts), so chunks stay >= 4096 blocks while aiming at ~48 K wave tasks for load
-        // balance; only a launch that could not otherwise fill the chip (one small image) splits finer.
         long long want = (49152 + base_waves - 1) / base_waves;
         long long cap = g.Nd / 4096;
         if (cap < 1) cap = 1;
@@ -235,7 +236,16 @@ int valu_sweep(fic_ctx* c, int tile0, int ntiles, hipStream_t s, int* nchunks_ou
         }
         nchunks = (int)(nc < 1 ? 1 : nc);
     }
-    if (nchunks > g.Nd) nchunks = g.Nd;
+    return nchunks > g.Nd ? g.Nd : nchunks;
+}
+
+// VALU sweep k_sweep_fast ("sweep" = 2) over tiles [tile0, tile0 + ntiles).
+int valu_sweep(fic_ctx* c, int tile0, int ntiles, hipStream_t s, int* nchunks_out)
+{
+    const FicGeom& g = c->g;
+    int NR, NC;
+    fic_fast_variant(g.B, g.n_iso, &NR, &NC);
+    int nchunks = valu_chunk_count(c, (long long)ntiles * (g.n_iso / NC) * g.planes);
     int chunk_len = (g.Nd + nchunks - 1) / nchunks;
     chunk_len = (chunk_len + 1) & ~1;              // even: the sweep consumes blocks in pairs
     nchunks = (g.Nd + chunk_len - 1) / chunk_len;
@@ -250,32 +260,15 @@ int d4_prep(fic_ctx* c, hipStream_t s)
 {
     const FicGeom& g = c->g;
     const size_t NW = (size_t)fic_d4_words(g.B), P = (size_t)g.planes;
-    if (!c->d4_rng) {
-        HIP_TRY(hipMalloc((void**)&c->d4_rng, P * g.tiles * NW * 64 * 4));
-        HIP_TRY(hipMalloc((void**)&c->d4_pool, P * g.Nd_pad * NW * 4));
-    }
+    if (!c->d4_rng) HIP_TRY(hipMalloc((void**)&c->d4_rng, P * g.tiles * NW * 64 * 4));
+    if (!c->d4_pool) HIP_TRY(hipMalloc((void**)&c->d4_pool, P * g.Nd_pad * NW * 4));
     if (fic_launch_d4_prep(c->b, c->d4_rng, c->d4_pool, g, s)) return fail(FIC_E_HIP, "k_range_d4 / k_pool_d4 launch failed");
     return FIC_OK;
 }
 int d4_sweep(fic_ctx* c, int tile0, int ntiles, hipStream_t s, int* nchunks_out)
 {
     const FicGeom& g = c->g;
-    const long long base_waves = (long long)ntiles * g.planes;
-    int nchunks = c->opt_chunks;
-    if (nchunks <= 0) {                                // same policy as valu_sweep
-        long long want = (49152 + base_waves - 1) / base_waves;
-        long long cap = g.Nd / 4096;
-        if (cap < 1) cap = 1;
-        long long nc = want < cap ? want : cap;
-        if (base_waves * nc < 4096) {
-            long long cap2 = g.Nd / 512;
-            if (cap2 < 1) cap2 = 1;
-            long long fill = (4096 + base_waves - 1) / base_waves;
-            nc = fill < cap2 ? fill : cap2;
-        }
-        nchunks = (int)(nc < 1 ? 1 : nc);
-    }
-    if (nchunks > g.Nd) nchunks = g.Nd;
+    int nchunks = valu_chunk_count(c, (long long)ntiles * g.planes);
     const int chunk_len = (g.Nd + nchunks - 1) / nchunks;
     nchunks = (g.Nd + chunk_len - 1) / chunk_len;
     if (fic_launch_sweep_d4(c->b, c->d4_rng, c->d4_pool, g, tile0, ntiles, chunk_len, nchunks, s))
@@ -315,20 +308,21 @@ int matrix_core_prep(fic_ctx* c, int kind, hipStream_t s)
     const FicGeom& g = c->g;
     const MatrixCoreShape m = matrix_core_shape(g, kind);
     const size_t P = (size_t)g.planes;
-    if (c->mfma_poolB && c->mfma_bf16 != (int)m.bf16) {     // operand type changed ("sweep" 3 <-> 4): new fragment stores
+    if ((c->mfma_poolB || c->mfma_rngA || c->mfma_sw || c->mfma_rconst) && c->mfma_bf16 != (int)m.bf16) {     // operand type changed ("sweep" 3 <-> 4): new fragment stores
         HIP_TRY(hipStreamSynchronize(s));
         void* old[] = {c->mfma_poolB, c->mfma_rngA, c->mfma_sw, c->mfma_rconst};
         for (void* p : old) if (p) (void)hipFree(p);
         c->mfma_poolB = c->mfma_rngA = c->mfma_sw = nullptr;
         c->mfma_rconst = nullptr;
     }
-    if (!c->mfma_poolB) {
+    {
+        // every store is guarded on its own pointer: a failed hipMalloc leaves the others usable and is retried next time
         c->mfma_bf16 = (int)m.bf16;
         const size_t rtiles = m.iso8 ? (size_t)m.ngroups8 * (m.G8 / 4) : (size_t)m.nctiles_alloc;   // 32-row/column range tiles
-        HIP_TRY(hipMalloc(&c->mfma_poolB, P * m.ndtiles_alloc * m.steps * 64 * 16));
-        HIP_TRY(hipMalloc(&c->mfma_rngA, P * rtiles * m.steps * 64 * 16));
-        HIP_TRY(hipMalloc(&c->mfma_sw, P * m.ndtiles_alloc * 32 * 8));
-        if (!m.bf16)
+        if (!c->mfma_poolB) HIP_TRY(hipMalloc(&c->mfma_poolB, P * m.ndtiles_alloc * m.steps * 64 * 16));
+        if (!c->mfma_rngA) HIP_TRY(hipMalloc(&c->mfma_rngA, P * rtiles * m.steps * 64 * 16));
+        if (!c->mfma_sw) HIP_TRY(hipMalloc(&c->mfma_sw, P * m.ndtiles_alloc * 32 * 8));
+        if (!m.bf16 && !c->mfma_rconst)
             HIP_TRY(hipMalloc((void**)&c->mfma_rconst, m.iso8 ? P * rtiles * 16 * sizeof(int) : P * rtiles * 32 * 16));
     }
     if (m.bf16) {
@@ -476,6 +470,7 @@ fic_ctx* fic_ctx_create(int device, int w, int h, int B, int wK, int n_iso, int 
     A(dev_alloc(&c->o.b, P * g.Nr));
     A(dev_alloc(&c->o.err, P * g.Nr));
     A(dev_alloc(&c->o.qrows, P * g.Nr * 3));
+    A(dev_alloc(&c->o.records, P * g.Nr * 6));
     if (rc == FIC_OK) {
         // zero the pool once: the FIC_POOL_PAD tail blocks stay zero forever (prefetch over-read)
         hipError_t e = hipMemset(c->b.pool_pix, 0, P * g.Nd_pad * g.n);
@@ -508,6 +503,7 @@ int fic_ctx_set_gray_host(fic_ctx* c, const uint8_t* gray)
     HIP_TRY(hipSetDevice(c->device));
     size_t bytes = (size_t)c->g.planes * c->g.W * c->g.H;
     if (!c->gray_own) { int rc = dev_alloc(&c->gray_own, bytes); if (rc) return rc; }
+    HIP_TRY(hipStreamSynchronize(c->last_stream));   // a previous encode on a non-blocking stream may still read gray_own
     HIP_TRY(hipMemcpy(c->gray_own, gray, bytes, hipMemcpyHostToDevice));
     c->b.gray = c->gray_own;
     c->have_input = true;
@@ -522,6 +518,7 @@ int fic_ctx_set_argb_host(fic_ctx* c, const int32_t* argb)
     size_t npix = (size_t)c->g.planes * c->g.W * c->g.H;
     if (!c->gray_own) { int rc = dev_alloc(&c->gray_own, npix); if (rc) return rc; }
     if (!c->argb_stage) { int rc = dev_alloc(&c->argb_stage, npix); if (rc) return rc; }
+    HIP_TRY(hipStreamSynchronize(c->last_stream));
     HIP_TRY(hipMemcpy(c->argb_stage, argb, npix * sizeof(int32_t), hipMemcpyHostToDevice));
     if (fic_launch_argb_to_gray(c->argb_stage, c->gray_own, npix, nullptr)) return fail(FIC_E_HIP, "k_argb_to_gray launch failed");
     HIP_TRY(hipStreamSynchronize(nullptr));
@@ -556,18 +553,22 @@ int fic_ctx_encode(fic_ctx* c, int range_begin, int range_count, void* hip_strea
     // which sweep
     int kind = c->opt_sweep;
     if (kind == 0) {
-        // full search: the VALU sweep; with 8 isometries at B = 8 its group-Fourier form (k_sweep_d4: 48 v_dot2c per pair
-        // instead of 128 v_dot4, same integers) -- "sweep" = 2 still selects k_sweep_fast there
-        kind = !g.full ? 1 : d4_available(g) ? 5 : 2;
-        // FIC_SWEEP=3 opts the whole process into the matrix-core sweep wherever it is built (same results);
-        // other geometries keep the VALU sweep.  An explicit fic_ctx_set_option("sweep", ...) wins.
-        const char* env = getenv("FIC_SWEEP");
-        // Small launches stay on the VALU sweep, where it is faster: the bf16-operand kernels (B = 4/8) win from about
-        // one 512x512 image (6.4e7 (range, domain) pairs: 0.19 vs 0.45 ms) upwards, the i8-operand kernels (B = 16)
-        // need ~5e8 pairs to amortise their per-chunk start-up.
+        // Windowed search: the generic kernel.  Full search: the matrix-core sweep -- bit-identical to the VALU sweeps
+        // and 2.8-5x faster (north_star's "no MFMA" premise is refuted by its own evidence:
+        // profiles/r01z_cfg2_default_pmc_summary.txt, 0.7 % of HBM peak, VALU busy 93.5 %).  Small launches stay on the
+        // VALU sweep where it is faster: the bf16-operand kernels (B = 4/8) win from about one 512x512 image (6.4e7
+        // (range, domain) pairs) upwards, the i8-operand kernels (B = 16) need ~5e8 pairs to amortise their start-up.
+        // FIC_SWEEP=<n> overrides the automatic choice process-wide wherever kernel n applies ("sweep" option wins).
         const long long pairs = (long long)g.planes * range_count * g.Nd;
         const long long enough = g.B <= 8 ? 50000000LL : 500000000LL;
-        if (env && env[0] == '3' && env[1] == '\0' && g.full && pairs >= enough) kind = 3;
+        const int valu = d4_available(g) ? 5 : 2;
+        kind = !g.full ? 1 : (pairs >= enough ? 3 : valu);
+        const char* env = getenv("FIC_SWEEP");
+        if (env && env[0] >= '1' && env[0] <= '5' && env[1] == '\0' && g.full) {
+            const int want = env[0] - '0';
+            if (want == 5) kind = valu;                       // "the VALU default": d4 where built, else k_sweep_fast
+            else if (want >= 2) kind = want;
+        }
     }
     if (kind >= 2 && !g.full) return fail(FIC_E_ARGUMENT, "fast sweep needs full search (wK == Dw == Dh)");
     if (kind == 5 && !d4_available(g)) return fail(FIC_E_ARGUMENT, "sweep 5 (k_sweep_d4) needs full search, n_iso = 8 and B = 8");
@@ -647,6 +648,13 @@ int fic_ctx_result_device_ptrs(fic_ctx* c, void** idx_local, void** a, void** b,
     if (qrows) *qrows = c->o.qrows;
     if (idx_global) *idx_global = c->o.idx_global;
     if (err) *err = c->o.err;
+    return FIC_OK;
+}
+
+int fic_ctx_records_device_ptr(fic_ctx* c, void** records)
+{
+    if (!c || !records) return fail(FIC_E_ARGUMENT, "fic_ctx_records_device_ptr: null argument");
+    *records = c->o.records;
     return FIC_OK;
 }
 

@@ -34,6 +34,7 @@ struct FicOutputs {
     float* b;             // unquantised brightness imageInfo[j][2]
     float* err;           // winning error (diagnostic)
     int32_t* qrows;       // writeData rows: (int)idx, (int)(a*100), (int)b   (FC:242-244)
+    int32_t* records;     // [planes][Nr][6] {idx_local, a bits, b bits, iso, (int)(a*100), (int)b}: the unit of the multi-GPU gather
 };
 
 int fic_launch_argb_to_gray(const int32_t* argb, uint8_t* gray, size_t npix, hipStream_t s);

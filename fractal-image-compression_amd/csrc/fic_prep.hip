@@ -244,6 +244,14 @@ __global__ __launch_bounds__(256) void k_finalize(const uint32_t* __restrict__ p
     out.a[o] = a;
     out.b[o] = b;
     out.err[o] = f32_from_orderable((uint32_t)(kk >> 32));
+    // the same row once more as one 24-byte record: what a rank contributes to the codebook gather
+    int32_t* rec = out.records + 6 * o;
+    rec[0] = wloc;
+    rec[1] = (int32_t)__float_as_uint(a);
+    rec[2] = (int32_t)__float_as_uint(b);
+    rec[3] = k;
+    rec[4] = out.qrows[3 * o + 1];
+    rec[5] = out.qrows[3 * o + 2];
 }
 
 // ---------------------------------------------------------------------------------------------

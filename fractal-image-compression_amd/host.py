@@ -163,6 +163,13 @@ class Encoder:
                 "iso": t(p[3], (P, N), "<i4"), "qrows": t(p[4], (P, N, 3), "<i4"),
                 "idx_global": t(p[5], (P, N), "<i4"), "err": t(p[6], (P, N), "<f4")}
 
+    def records_device(self):
+        """torch int32 tensor [planes, N_r, 6] aliasing the context's packed codebook records (the unit of the gather)."""
+        import torch
+        p = C.c_void_p()
+        capi.check(capi.lib().fic_ctx_records_device_ptr(self._h, C.byref(p)))
+        return torch.as_tensor(_DevArray(p.value, (self.planes, self.n_ranges, 6), "<i4"), device=torch.device("cuda", self.device))
+
     def collage(self):
         out = np.zeros((self.planes, self.height * self.width), np.int32)
         capi.check(capi.lib().fic_ctx_collage_host(self._h, capi.ptr(out, C.c_int32)))

@@ -114,6 +114,12 @@ FIC_API int fic_ctx_get_results_host(fic_ctx* ctx, int32_t* idx_local, float* a,
 FIC_API int fic_ctx_result_device_ptrs(fic_ctx* ctx, void** idx_local, void** a, void** b, void** iso, void** qrows,
                                        void** idx_global, void** err);
 
+/* The same rows packed as the unit of the multi-GPU codebook gather: device pointer to int32
+ * [planes][N_r][6] = {idx_local, a bits, b bits, iso, (int)(a*100), (int)b} (imageInfo[j] of
+ * FractalCompression.java:156 + the ints writeData emits, :242-244), written by every fic_ctx_encode for the range
+ * span it covered.  Owned by the context. */
+FIC_API int fic_ctx_records_device_ptr(fic_ctx* ctx, void** records);
+
 /* getBestGeneratedCollage (FractalCompression.java:269-300): grey ARGB [planes][h][w] of the
  * one-step collage from the unquantised a,b of the last encode (all ranges must be encoded). */
 FIC_API int fic_ctx_collage_host(fic_ctx* ctx, int32_t* argb_out);

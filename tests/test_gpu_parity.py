@@ -104,7 +104,7 @@ FULL_CASES = [  # image, B, n_iso
 
 
 @pytest.mark.parametrize("name,B,n_iso", FULL_CASES)
-@pytest.mark.parametrize("sweep", [2, 1], ids=["fast", "generic"])
+@pytest.mark.parametrize("sweep", [0, 2, 1], ids=["default", "fast", "generic"])
 def test_full_search_matches_oracle(oracle, name, B, n_iso, sweep):
     """Config 1 (Lena64, B=4, full) and friends: full search == widthKernel = Dw (FC:89-96)."""
     g = IMAGES[name]
