@@ -71,6 +71,8 @@ def lib():
         "fic_is_greyscale_argb": (C.c_int, [i32p, C.c_int, C.c_int]),
         "fic_encode_gray_argb": (C.c_int, [i32p] + [C.c_int] * 6 + [i32p, f32p, f32p, i32p, i32p]),
         "fic_encode_gray_u8": (C.c_int, [u8p] + [C.c_int] * 6 + [i32p, f32p, f32p, i32p, i32p]),
+        "fic_encode_gray_argb_multi": (C.c_int, [i32p] + [C.c_int] * 6 + [i32p, f32p, f32p, i32p, i32p]),
+        "fic_encode_gray_u8_multi": (C.c_int, [u8p] + [C.c_int] * 6 + [i32p, f32p, f32p, i32p, i32p]),
         "fic_write_run_gray": (C.c_int64, [i32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, u8p, C.c_int64]),
         "fic_ctx_create": (vp, [C.c_int] * 7),
         "fic_ctx_destroy": (None, [vp]),
@@ -90,6 +92,8 @@ def lib():
         "fic_ctx_set_option": (C.c_int, [vp, C.c_char_p, C.c_int]),
         "fic_ctx_sweep_time": (C.c_int, [vp, C.POINTER(C.c_double), ip, C.c_int]),
         "fic_ctx_info": (C.c_int, [vp, ip]),
+        "fic_ctx_sweep_stats": (C.c_int, [vp, C.POINTER(C.c_uint64), C.c_int]),
+        "fic_debug_rccl_selftest": (C.c_int, [C.c_int]),
         "fic_debug_sqrt_f64": (C.c_int, [C.c_int, C.c_uint32, C.c_uint32, C.POINTER(C.c_double)]),
         "fic_ctx_debug_pool_host": (C.c_int, [vp, u8p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), u8p]),
     }
@@ -149,6 +153,21 @@ def encode_gray_oneshot(gray, B, wK, n_iso=1, device=0):
     check(lib().fic_encode_gray_u8(ptr(g, C.c_uint8), w, h, B, Dw if wK is None else wK, n_iso, device,
                                    ptr(r["idx_local"], C.c_int32), ptr(r["a"], C.c_float), ptr(r["b"], C.c_float),
                                    ptr(r["iso"], C.c_int32), ptr(r["qrows"], C.c_int32)))
+    return r
+
+
+def encode_gray_multi(gray, B, wK, n_iso=1, n_gpus=1):
+    """fic_encode_gray_u8_multi: one synchronous call, range blocks sharded over the first n_gpus devices, RCCL gather in
+    the library (what the JNI host calls on a multi-GPU node)."""
+    g = np.ascontiguousarray(gray, np.uint8)
+    h, w = g.shape
+    Rw, Rh, Dw, Dh = geometry(w, h, B)
+    nr = Rw * Rh
+    r = {"idx_local": np.zeros(nr, np.int32), "a": np.zeros(nr, np.float32), "b": np.zeros(nr, np.float32),
+         "iso": np.zeros(nr, np.int32), "qrows": np.zeros((nr, 3), np.int32)}
+    check(lib().fic_encode_gray_u8_multi(ptr(g, C.c_uint8), w, h, B, Dw if wK is None else wK, n_iso, n_gpus,
+                                         ptr(r["idx_local"], C.c_int32), ptr(r["a"], C.c_float), ptr(r["b"], C.c_float),
+                                         ptr(r["iso"], C.c_int32), ptr(r["qrows"], C.c_int32)))
     return r
 
 

@@ -2,6 +2,8 @@
 // validation, device buffers, launch order, result copies.  No compute happens on the CPU and
 // there is no CPU fallback: without a HIP device every compute entry returns FIC_E_NO_DEVICE.
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+#include <dlfcn.h>
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -99,11 +101,18 @@ struct fic_ctx {
     void* mfma_sw = nullptr;
     int* mfma_rconst = nullptr;
     int mfma_bf16 = 0;               // operand type the fragment stores were built for
+    void* q_pool = nullptr;          // k_sweep_q ("sweep" = 6): A fragments, flat-tile flags, B fragments, error bounds, u8 copies
+    void* q_flat = nullptr;
+    void* q_rng = nullptr;
+    void* q_E = nullptr;
+    void* q_u8 = nullptr;
+    unsigned long long* q_stats = nullptr;   // "sweep_stats" = 1: device counters of k_sweep_q (fic_ctx_sweep_stats)
     uint32_t* d4_rng = nullptr;      // k_sweep_d4: range / domain slots of the group-Fourier form (n_iso = 8, B = 8 / 16)
     uint32_t* d4_pool = nullptr;
     bool have_input = false;
     bool encoded_any = false;
     hipStream_t last_stream = nullptr;
+    hipStream_t own_stream = nullptr; // non-blocking stream of the multi-device entry (created on demand)
     int opt_sweep = 0, opt_chunks = 0, opt_time = 0;
     int last_chunks = 0, last_kind = 0;
     std::vector<hipEvent_t> ev;      // pairs start/stop
@@ -126,7 +135,8 @@ int ctx_free_all(fic_ctx* c)
     (void)hipSetDevice(c->device);
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
     c->ev.clear();
-    void* ptrs[] = {c->gray_own, c->argb_stage, c->collage, c->decoded, c->mfma_poolB, c->mfma_rngA, c->mfma_sw, c->mfma_rconst, c->d4_rng, c->d4_pool, c->b.scaled, c->b.pool_pix, c->b.pool_st, c->b.pool_var,
+    if (c->own_stream) { (void)hipStreamDestroy(c->own_stream); c->own_stream = nullptr; }
+    void* ptrs[] = {c->gray_own, c->argb_stage, c->collage, c->decoded, c->mfma_poolB, c->mfma_rngA, c->mfma_sw, c->mfma_rconst, c->q_pool, c->q_flat, c->q_rng, c->q_E, c->q_u8, c->q_stats, c->d4_rng, c->d4_pool, c->b.scaled, c->b.pool_pix, c->b.pool_st, c->b.pool_var,
                     c->b.pool_s64, c->b.rng_pix, c->b.rng_st, c->b.key, c->o.idx_local, c->o.idx_global, c->o.iso,
                     c->o.a, c->o.b, c->o.err, c->o.qrows, c->o.records};
     for (void* p : ptrs)
@@ -152,7 +162,7 @@ int flush_events(fic_ctx* c)
 // Idle single-plane contexts of the one-shot entry points, most recently used last.
 std::mutex g_cache_mu;
 std::vector<fic_ctx*> g_cache;
-constexpr size_t kCacheSlots = 4;
+constexpr size_t kCacheSlots = 16;   // the multi-device entry parks one context per device
 
 fic_ctx* cache_take(int device, int w, int h, int B, int wK, int n_iso)
 {
@@ -384,6 +394,68 @@ int matrix_core_sweep(fic_ctx* c, int kind, int tile0, int tile1, hipStream_t s,
     return FIC_OK;
 }
 
+// Default full-search sweep (fic_q.hip): shapes of its stores, fused prep (pool build + range prep + fragments), launch.
+struct QShape {
+    int ndtiles, ndtiles_alloc;      // domain tiles (x32 blocks), + 2 spare for the prefetch
+    int CT;                          // column tiles (x32 range copies) per workgroup
+    int nct_alloc;                   // column tiles allocated (padded for the last workgroup)
+};
+QShape q_shape(const FicGeom& g)
+{
+    QShape q;
+    q.ndtiles = (g.Nd + 31) / 32;
+    q.ndtiles_alloc = q.ndtiles + 2;
+    q.CT = fic_q_ct(g.B);
+    const int nct = g.Nr_pad * fic_q_cols_per_range(g.B, g.n_iso) / 32;
+    q.nct_alloc = (nct + q.CT - 1) / q.CT * q.CT + q.CT;
+    return q;
+}
+int q_prep(fic_ctx* c, int tile0, int tile1, hipStream_t s)
+{
+    const FicGeom& g = c->g;
+    const QShape q = q_shape(g);
+    const size_t P = (size_t)g.planes, NK = (size_t)g.n / 16;
+    if (!c->q_pool) HIP_TRY(hipMalloc(&c->q_pool, P * q.ndtiles_alloc * NK * 64 * 16));
+    if (!c->q_flat) HIP_TRY(hipMalloc(&c->q_flat, P * q.ndtiles_alloc * sizeof(uint32_t)));
+    if (!c->q_rng) {                                   // zeroed once: column tiles past the last range group stay zero fragments
+        HIP_TRY(hipMalloc(&c->q_rng, P * q.nct_alloc * NK * 64 * 16));
+        HIP_TRY(hipMemsetAsync(c->q_rng, 0, P * q.nct_alloc * NK * 64 * 16, s));
+    }
+    if (!c->q_E) HIP_TRY(hipMalloc(&c->q_E, P * g.Nr_pad * sizeof(float)));
+    if (!c->q_u8) HIP_TRY(hipMalloc(&c->q_u8, P * g.Nr_pad * g.n_iso * g.n));
+    const int tsz = 64 * g.NR;
+    const int grp0 = tile0 * tsz / 64, grp1 = tile1 * tsz / 64;      // 64-range groups covering the span
+    if (fic_launch_q_prep(c->b, c->q_pool, c->q_flat, c->q_rng, c->q_E, c->q_u8, g, q.ndtiles_alloc, q.nct_alloc, grp0, grp1 - grp0, s))
+        return fail(FIC_E_HIP, "k_pool_q / k_range_q launch failed");
+    return FIC_OK;
+}
+int q_sweep(fic_ctx* c, int tile0, int tile1, hipStream_t s, int* nchunks_out)
+{
+    const FicGeom& g = c->g;
+    const QShape q = q_shape(g);
+    const int tsz = 64 * g.NR;
+    const int cpr = fic_q_cols_per_range(g.B, g.n_iso);
+    const int ct_begin = tile0 * tsz * cpr / 32, ct_end = tile1 * tsz * cpr / 32;
+    int nchunks = c->opt_chunks;
+    if (nchunks <= 0) {
+        // a chunk's start-up is about one domain tile of extra work per range (fic_q.hip), so chunks only need to be
+        // long enough to hide that (>= 16 tiles) and numerous enough to fill the chip (~8 workgroups per CU)
+        const long long base_wg = (long long)((ct_end - ct_begin + q.CT - 1) / q.CT) * g.planes;
+        long long want = (2048 + base_wg - 1) / base_wg;
+        long long cap = q.ndtiles / 16;
+        if (cap < 1) cap = 1;
+        nchunks = (int)(want < cap ? want : cap);
+    }
+    if (nchunks > q.ndtiles) nchunks = q.ndtiles;
+    const int tiles_per_chunk = (q.ndtiles + nchunks - 1) / nchunks;
+    nchunks = (q.ndtiles + tiles_per_chunk - 1) / tiles_per_chunk;
+    if (fic_launch_sweep_q(c->b, c->q_pool, c->q_flat, c->q_rng, c->q_E, c->q_u8, g, ct_begin, ct_end, q.ndtiles, q.ndtiles_alloc,
+                           q.nct_alloc, tiles_per_chunk, nchunks, s, c->q_stats))
+        return fail(FIC_E_HIP, "k_sweep_q launch failed");
+    *nchunks_out = nchunks;
+    return FIC_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -553,47 +625,51 @@ int fic_ctx_encode(fic_ctx* c, int range_begin, int range_count, void* hip_strea
     // which sweep
     int kind = c->opt_sweep;
     if (kind == 0) {
-        // Windowed search: the generic kernel.  Full search: the matrix-core sweep -- bit-identical to the VALU sweeps
-        // and 2.8-5x faster (north_star's "no MFMA" premise is refuted by its own evidence:
-        // profiles/r01z_cfg2_default_pmc_summary.txt, 0.7 % of HBM peak, VALU busy 93.5 %).  Small launches stay on the
-        // VALU sweep where it is faster: the bf16-operand kernels (B = 4/8) win from about one 512x512 image (6.4e7
-        // (range, domain) pairs) upwards, the i8-operand kernels (B = 16) need ~5e8 pairs to amortise their start-up.
-        // FIC_SWEEP=<n> overrides the automatic choice process-wide wherever kernel n applies ("sweep" option wins).
+        // Windowed search: the generic kernel.  Full search: the matrix-core sweep k_sweep_q (fic_q.hip) -- same codebook
+        // bits as the VALU sweeps, several times faster (north_star's "no MFMA" premise is refuted by
+        // the evidence it asked for: profiles/r01z_cfg2_default_pmc_summary.txt, 0.7 % of HBM peak, VALU busy 93.5 %).
+        // Very small launches stay on the VALU sweep (no fragment prep).
+        // FIC_SWEEP=<n> overrides the automatic choice process-wide wherever kernel n applies ("sweep" option wins);
+        // FIC_SWEEP=5 means "the VALU-only default": k_sweep_d4 where it is built, else k_sweep_fast.
         const long long pairs = (long long)g.planes * range_count * g.Nd;
-        const long long enough = g.B <= 8 ? 50000000LL : 500000000LL;
         const int valu = d4_available(g) ? 5 : 2;
-        kind = !g.full ? 1 : (pairs >= enough ? 3 : valu);
+        kind = !g.full ? 1 : (pairs >= 2000000LL ? 6 : valu);
         const char* env = getenv("FIC_SWEEP");
-        if (env && env[0] >= '1' && env[0] <= '5' && env[1] == '\0' && g.full) {
+        if (env && env[0] >= '2' && env[0] <= '6' && env[1] == '\0' && g.full) {
             const int want = env[0] - '0';
-            if (want == 5) kind = valu;                       // "the VALU default": d4 where built, else k_sweep_fast
-            else if (want >= 2) kind = want;
+            kind = want == 5 ? valu : want;
         }
     }
     if (kind >= 2 && !g.full) return fail(FIC_E_ARGUMENT, "fast sweep needs full search (wK == Dw == Dh)");
     if (kind == 5 && !d4_available(g)) return fail(FIC_E_ARGUMENT, "sweep 5 (k_sweep_d4) needs full search, n_iso = 8 and B = 8");
-    // pool build (createCodebuch FC:119) + range prep
-    if (fic_launch_scale(c->b.gray, c->b.scaled, g, s)) return fail(FIC_E_HIP, "k_scale launch failed");
-    if (fic_launch_pool(c->b.scaled, c->b.pool_pix, c->b.pool_st, c->b.pool_var, c->b.pool_s64, g, s))
-        return fail(FIC_E_HIP, "k_pool launch failed");
-    // k_sweep_d4 reads its own slot store and the finaliser reads the image: no isometry copies to build then
-    if (fic_launch_range(c->b.gray, c->b.rng_pix, c->b.rng_st, g, s, kind == 5 ? 0 : 1)) return fail(FIC_E_HIP, "k_range launch failed");
-
     const int tsz = 64 * g.NR;
     const int tile0 = range_begin / tsz;
     const int tile1 = (range_begin + range_count + tsz - 1) / tsz;
     const int ntiles = tile1 - tile0;
-    // one 2-D fill: rows = planes (pitch Nr_pad keys), width = the tile span of this shard
-    HIP_TRY(hipMemset2DAsync(c->b.key + (size_t)tile0 * tsz, (size_t)g.Nr_pad * sizeof(unsigned long long), 0xFF,
-                             (size_t)ntiles * tsz * sizeof(unsigned long long), (size_t)g.planes, s));
     int nchunks = 1;
     int rc = FIC_OK;
-    if (kind == 5) rc = d4_prep(c, s);
-    else if (kind >= 3) rc = matrix_core_prep(c, kind, s);              // fragment prep belongs to pool build / range prep: not timed
+    // pool build (createCodebuch FC:119) + range prep
+    if (fic_launch_scale(c->b.gray, c->b.scaled, g, s)) return fail(FIC_E_HIP, "k_scale launch failed");
+    if (kind == 6) {
+        // fused: k_pool_q = pool + statistics + A fragments, k_range_q = range statistics + key reset + copies + B fragments
+        rc = q_prep(c, tile0, tile1, s);
+    } else {
+        if (fic_launch_pool(c->b.scaled, c->b.pool_pix, c->b.pool_st, c->b.pool_var, c->b.pool_s64, g, s))
+            return fail(FIC_E_HIP, "k_pool launch failed");
+        // k_sweep_d4 reads its own slot store and the finaliser reads the image: no isometry copies to build then
+        if (fic_launch_range(c->b.gray, c->b.rng_pix, c->b.rng_st, g, s, kind == 5 ? 0 : 1)) return fail(FIC_E_HIP, "k_range launch failed");
+        // one 2-D fill: rows = planes (pitch Nr_pad keys), width = the tile span of this shard
+        HIP_TRY(hipMemset2DAsync(c->b.key + (size_t)tile0 * tsz, (size_t)g.Nr_pad * sizeof(unsigned long long), 0xFF,
+                                 (size_t)ntiles * tsz * sizeof(unsigned long long), (size_t)g.planes, s));
+        if (kind == 5) rc = d4_prep(c, s);
+        else if (kind >= 3) rc = matrix_core_prep(c, kind, s);          // fragment prep belongs to pool build / range prep: not timed
+    }
     if (rc == FIC_OK) rc = time_begin(c, s);
     if (rc == FIC_OK) {
         if (kind == 1) {
             if (fic_launch_sweep_generic(c->b, g, range_begin, range_count, s)) rc = fail(FIC_E_HIP, "k_sweep_generic launch failed");
+        } else if (kind == 6) {
+            rc = q_sweep(c, tile0, tile1, s, &nchunks);
         } else if (kind == 5) {
             rc = d4_sweep(c, tile0, tile1 - tile0, s, &nchunks);
         } else if (kind >= 3) {
@@ -606,7 +682,8 @@ int fic_ctx_encode(fic_ctx* c, int range_begin, int range_count, void* hip_strea
     if (rc != FIC_OK) return rc;
     c->last_chunks = nchunks;
     c->last_kind = kind;
-    if (fic_launch_finalize(c->b, c->o, g, range_begin, range_count, s, kind == 5 ? 1 : 0)) return fail(FIC_E_HIP, "k_finalize launch failed");
+    // kinds 5 and 6 build no lane-transposed isometry copies: the finaliser recomputes the winner's covariance from the image
+    if (fic_launch_finalize(c->b, c->o, g, range_begin, range_count, s, (kind == 5 || kind == 6) ? 1 : 0)) return fail(FIC_E_HIP, "k_finalize launch failed");
     c->encoded_any = true;
     return FIC_OK;
 }
@@ -676,14 +753,24 @@ int fic_ctx_set_option(fic_ctx* c, const char* name, int value)
 {
     if (!c || !name) return fail(FIC_E_ARGUMENT, "fic_ctx_set_option: null argument");
     if (!strcmp(name, "sweep")) {
-        if (value < 0 || value > 5)
-            return fail(FIC_E_ARGUMENT, "sweep must be 0 (auto), 1 (generic), 2 (fast, VALU), 3 (matrix-core), 4 (matrix-core, i8 operands) or 5 (VALU, group-Fourier isometries)");
+        if (value < 0 || value > 6)
+            return fail(FIC_E_ARGUMENT, "sweep must be 0 (auto), 1 (generic), 2 (fast, VALU), 3 (matrix-core, exact covariances), 4 (matrix-core, i8 operands), 5 (VALU, group-Fourier isometries) or 6 (matrix-core, normalised f16 prune GEMM)");
         c->opt_sweep = value;
     } else if (!strcmp(name, "chunks")) {
         if (value < 0) return fail(FIC_E_ARGUMENT, "chunks must be >= 0");
         c->opt_chunks = value;
     } else if (!strcmp(name, "time_sweep")) {
         c->opt_time = value ? 1 : 0;
+    } else if (!strcmp(name, "sweep_stats")) {
+        HIP_TRY(hipSetDevice(c->device));
+        if (value && !c->q_stats) {
+            HIP_TRY(hipMalloc((void**)&c->q_stats, 4 * sizeof(unsigned long long)));
+            HIP_TRY(hipMemset(c->q_stats, 0, 4 * sizeof(unsigned long long)));
+        } else if (!value && c->q_stats) {
+            HIP_TRY(hipStreamSynchronize(c->last_stream));
+            (void)hipFree(c->q_stats);
+            c->q_stats = nullptr;
+        }
     } else {
         return fail(FIC_E_ARGUMENT, "unknown option '%s'", name);
     }
@@ -700,6 +787,18 @@ int fic_ctx_sweep_time(fic_ctx* c, double* total_ms, int* launches, int reset)
     if (total_ms) *total_ms = c->acc_ms;
     if (launches) *launches = c->acc_n;
     if (reset) { c->acc_ms = 0.0; c->acc_n = 0; }
+    return FIC_OK;
+}
+
+int fic_ctx_sweep_stats(fic_ctx* c, uint64_t* out4, int reset)
+{
+    if (!c || !out4) return fail(FIC_E_ARGUMENT, "fic_ctx_sweep_stats: null argument");
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (!c->q_stats) return fail(FIC_E_STATE, "fic_ctx_sweep_stats: set the option \"sweep_stats\" first");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->last_stream));
+    HIP_TRY(hipMemcpy(out4, c->q_stats, 4 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    if (reset) HIP_TRY(hipMemset(c->q_stats, 0, 4 * sizeof(uint64_t)));
     return FIC_OK;
 }
 
@@ -1056,6 +1155,7 @@ int64_t fic_write_run_rgb(const int32_t* qrows5, int n_ranges, int w, int h, int
     return need;
 }
 
+static void fic_release_comms_();
 static int encode_oneshot(const uint8_t* gray, const int32_t* argb, int w, int h, int B, int wK, int n_iso, int device,
                           int32_t* idx_local, float* a, float* b, int32_t* iso, int32_t* qrows)
 {
@@ -1095,6 +1195,7 @@ void fic_release_cache(void)
         r->free_all();
         delete r;
     }
+    fic_release_comms_();
 }
 
 int fic_encode_gray_argb(const int32_t* argb, int w, int h, int B, int wK, int n_iso, int device, int32_t* idx_local,
@@ -1107,6 +1208,272 @@ int fic_encode_gray_u8(const uint8_t* gray, int w, int h, int B, int wK, int n_i
                        float* a, float* b, int32_t* iso, int32_t* qrows)
 {
     return encode_oneshot(gray, nullptr, w, h, B, wK, n_iso, device, idx_local, a, b, iso, qrows);
+}
+
+// ---- in-library multi-device encode (SURVEY.md 8b "n_gpus", 8e) -------------------------------------------------
+// FractalCompression.encode (FC:54-59) is ONE synchronous call on one host thread; the range loop it replaces
+// (FC:125-159) carries no state between iterations, so the call shards its range blocks over n_gpus devices from that
+// one thread: one context and one non-blocking stream per device, tile-aligned spans (the rule of sharding.shard_spans),
+// every device builds its own replica of the pool from the replicated image, and the 24-byte codebook records are
+// gathered to device 0 with ONE grouped RCCL send/recv (latency-bound on xGMI; no ring, no all-reduce).
+// RCCL is loaded on first use (librccl.so.1): a single-GPU host needs no RCCL.
+namespace {
+
+struct Rccl {
+    void* lib = nullptr;
+    decltype(&ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclSend) Send = nullptr;
+    decltype(&ncclRecv) Recv = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    std::vector<int> devs;               // devices of the live communicators
+    std::vector<ncclComm_t> comms;
+};
+std::mutex g_multi_mu;
+Rccl g_rccl;
+
+int rccl_load()
+{
+    if (g_rccl.lib) return FIC_OK;
+    void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) return fail(FIC_E_HIP, "multi-device encode needs RCCL: %s", dlerror());
+#define FIC_RCCL_SYM(field, name)                                                                   \
+    g_rccl.field = (decltype(g_rccl.field))dlsym(h, name);                                          \
+    if (!g_rccl.field) { dlclose(h); return fail(FIC_E_HIP, "librccl lacks %s", name); }
+    FIC_RCCL_SYM(CommInitAll, "ncclCommInitAll")
+    FIC_RCCL_SYM(CommDestroy, "ncclCommDestroy")
+    FIC_RCCL_SYM(GroupStart, "ncclGroupStart")
+    FIC_RCCL_SYM(GroupEnd, "ncclGroupEnd")
+    FIC_RCCL_SYM(Send, "ncclSend")
+    FIC_RCCL_SYM(Recv, "ncclRecv")
+    FIC_RCCL_SYM(GetErrorString, "ncclGetErrorString")
+#undef FIC_RCCL_SYM
+    g_rccl.lib = h;
+    return FIC_OK;
+}
+void rccl_drop_comms()
+{
+    for (ncclComm_t c : g_rccl.comms)
+        if (c) (void)g_rccl.CommDestroy(c);
+    g_rccl.comms.clear();
+    g_rccl.devs.clear();
+}
+#define RCCL_TRY(expr)                                                                              \
+    do {                                                                                            \
+        ncclResult_t r_ = (expr);                                                                   \
+        if (r_ != ncclSuccess) return fail(FIC_E_HIP, "%s: %s", #expr, g_rccl.GetErrorString(r_));  \
+    } while (0)
+// one communicator per device, created once per device list and kept (ncclCommInitAll costs ~a second)
+int rccl_comms(const std::vector<int>& devs)
+{
+    int rc = rccl_load();
+    if (rc) return rc;
+    if (g_rccl.devs == devs && !g_rccl.comms.empty()) return FIC_OK;
+    rccl_drop_comms();
+    g_rccl.comms.assign(devs.size(), nullptr);
+    ncclResult_t r = g_rccl.CommInitAll(g_rccl.comms.data(), (int)devs.size(), devs.data());
+    if (r != ncclSuccess) {
+        g_rccl.comms.clear();
+        return fail(FIC_E_HIP, "ncclCommInitAll(%d devices): %s", (int)devs.size(), g_rccl.GetErrorString(r));
+    }
+    g_rccl.devs = devs;
+    return FIC_OK;
+}
+
+// gather of the span records [begin_i, begin_i + count_i) of every context's `records` array into context 0's
+int gather_rccl(const std::vector<fic_ctx*>& ctx, const std::vector<int>& begin, const std::vector<int>& count)
+{
+    std::vector<int> devs;
+    for (fic_ctx* c : ctx) devs.push_back(c->device);
+    int rc = rccl_comms(devs);
+    if (rc) return rc;
+    RCCL_TRY(g_rccl.GroupStart());
+    for (size_t i = 1; i < ctx.size(); i++) {
+        if (count[i] == 0) continue;
+        const size_t off = (size_t)begin[i] * 6, cnt = (size_t)count[i] * 6;
+        HIP_TRY(hipSetDevice(ctx[i]->device));
+        RCCL_TRY(g_rccl.Send(ctx[i]->o.records + off, cnt, ncclInt32, 0, g_rccl.comms[i], ctx[i]->own_stream));
+        HIP_TRY(hipSetDevice(ctx[0]->device));
+        RCCL_TRY(g_rccl.Recv(ctx[0]->o.records + off, cnt, ncclInt32, (int)i, g_rccl.comms[0], ctx[0]->own_stream));
+    }
+    RCCL_TRY(g_rccl.GroupEnd());
+    return FIC_OK;
+}
+// the same gather as plain device copies: logical shards that share a physical device (FIC_FAKE_DEVICES, a test knob --
+// RCCL refuses two ranks on one device) and FIC_GATHER=copy
+int gather_copy(const std::vector<fic_ctx*>& ctx, const std::vector<int>& begin, const std::vector<int>& count)
+{
+    for (size_t i = 1; i < ctx.size(); i++) {
+        if (count[i] == 0) continue;
+        const size_t off = (size_t)begin[i] * 6, bytes = (size_t)count[i] * 6 * sizeof(int32_t);
+        HIP_TRY(hipSetDevice(ctx[i]->device));
+        if (ctx[i]->device == ctx[0]->device)
+            HIP_TRY(hipMemcpyAsync(ctx[0]->o.records + off, ctx[i]->o.records + off, bytes, hipMemcpyDeviceToDevice, ctx[i]->own_stream));
+        else
+            HIP_TRY(hipMemcpyPeerAsync(ctx[0]->o.records + off, ctx[0]->device, ctx[i]->o.records + off, ctx[i]->device, bytes,
+                                       ctx[i]->own_stream));
+    }
+    for (size_t i = 1; i < ctx.size(); i++) {
+        HIP_TRY(hipSetDevice(ctx[i]->device));
+        HIP_TRY(hipStreamSynchronize(ctx[i]->own_stream));
+    }
+    return FIC_OK;
+}
+
+int encode_multi(const uint8_t* gray, const int32_t* argb, int w, int h, int B, int wK, int n_iso, int n_gpus,
+                 int32_t* idx_local, float* a, float* b, int32_t* iso, int32_t* qrows)
+{
+    if ((!gray && !argb) || !idx_local || !a || !b) return fail(FIC_E_ARGUMENT, "fic_encode_gray_multi: null argument");
+    if (n_gpus < 1) return fail(FIC_E_ARGUMENT, "n_gpus=%d", n_gpus);
+    FicGeom g;
+    int rc = make_geometry(w, h, B, wK, n_iso, 1, &g);
+    if (rc) return rc;
+    const int ndev = fic_device_count();
+    if (ndev <= 0) return fail(FIC_E_NO_DEVICE, "no HIP device visible (this library has no CPU path)");
+    const char* fake = getenv("FIC_FAKE_DEVICES");        // test knob: logical devices beyond the real ones share them round-robin
+    if (n_gpus > ndev && !(fake && atoi(fake) >= n_gpus))
+        return fail(FIC_E_NO_DEVICE, "n_gpus=%d but %d HIP device(s) visible", n_gpus, ndev);
+    const bool distinct = n_gpus <= ndev;
+    const char* gmode = getenv("FIC_GATHER");
+    const bool use_rccl = distinct && !(gmode && !strcmp(gmode, "copy"));
+    std::lock_guard<std::mutex> lk(g_multi_mu);
+    // tile-aligned spans: no sweep tile is computed twice (same rule as sharding.shard_spans)
+    const int tsz = 64 * g.NR;
+    std::vector<int> begin(n_gpus), count(n_gpus);
+    for (int r = 0; r < n_gpus; r++) {
+        const long long t0 = (long long)g.tiles * r / n_gpus, t1 = (long long)g.tiles * (r + 1) / n_gpus;
+        const int bb = (int)(t0 * tsz < g.Nr ? t0 * tsz : g.Nr), ee = (int)(t1 * tsz < g.Nr ? t1 * tsz : g.Nr);
+        begin[r] = bb;
+        count[r] = ee - bb;
+    }
+    std::vector<fic_ctx*> ctx(n_gpus, nullptr);
+    auto drop = [&](bool keep) {
+        const std::string keep_err = g_err;
+        const int keep_code = g_err_code;
+        for (fic_ctx* c : ctx)
+            if (c) { if (keep) cache_give(c); else fic_ctx_destroy(c); }
+        g_err = keep_err;
+        g_err_code = keep_code;
+    };
+    for (int i = 0; i < n_gpus && rc == FIC_OK; i++) {
+        const int dev = i % ndev;
+        ctx[i] = cache_take(dev, w, h, B, wK, n_iso);
+        if (!ctx[i]) ctx[i] = fic_ctx_create(dev, w, h, B, wK, n_iso, 1);
+        if (!ctx[i]) { rc = g_err_code ? g_err_code : FIC_E_HIP; break; }
+        if (!ctx[i]->own_stream) {
+            hipError_t e = hipSetDevice(dev);
+            if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx[i]->own_stream, hipStreamNonBlocking);
+            if (e != hipSuccess) { rc = fail(FIC_E_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); break; }
+        }
+        // the whole image on every device: each builds its own pool replica (cheaper than shipping the 16x-expanded pool)
+        rc = gray ? fic_ctx_set_gray_host(ctx[i], gray) : fic_ctx_set_argb_host(ctx[i], argb);
+    }
+    for (int i = 0; i < n_gpus && rc == FIC_OK; i++)
+        rc = fic_ctx_encode(ctx[i], begin[i], count[i], ctx[i]->own_stream);      // a rank without tiles: count 0, nothing launched
+    if (rc == FIC_OK) rc = use_rccl ? gather_rccl(ctx, begin, count) : gather_copy(ctx, begin, count);
+    std::vector<int32_t> rec;
+    if (rc == FIC_OK) {
+        rec.resize((size_t)g.Nr * 6);
+        hipError_t e = hipSetDevice(ctx[0]->device);
+        if (e == hipSuccess) e = hipMemcpyAsync(rec.data(), ctx[0]->o.records, rec.size() * sizeof(int32_t), hipMemcpyDeviceToHost, ctx[0]->own_stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx[0]->own_stream);
+        if (e != hipSuccess) rc = fail(FIC_E_HIP, "codebook copy: %s", hipGetErrorString(e));
+    }
+    if (rc != FIC_OK) {
+        // leave no stream with work in flight behind a failed call
+        for (fic_ctx* c : ctx)
+            if (c && c->own_stream) { (void)hipSetDevice(c->device); (void)hipStreamSynchronize(c->own_stream); }
+        drop(false);
+        return rc;
+    }
+    for (int j = 0; j < g.Nr; j++) {
+        const int32_t* r6 = &rec[(size_t)j * 6];
+        idx_local[j] = r6[0];
+        memcpy(&a[j], &r6[1], 4);
+        memcpy(&b[j], &r6[2], 4);
+        if (iso) iso[j] = r6[3];
+        if (qrows) { qrows[3 * j] = r6[0]; qrows[3 * j + 1] = r6[4]; qrows[3 * j + 2] = r6[5]; }
+    }
+    drop(true);
+    return FIC_OK;
+}
+
+}  // namespace
+
+// Test hook: loads RCCL, creates (and keeps) one communicator per device 0..n-1 and, for n >= 2, runs the gather's
+// grouped send/recv pattern on 6-int records.  Returns FIC_OK or a negative code.
+int fic_debug_rccl_selftest(int n)
+{
+    const int ndev = fic_device_count();
+    if (n < 1 || n > ndev) return fail(FIC_E_NO_DEVICE, "fic_debug_rccl_selftest: %d of %d devices", n, ndev);
+    std::lock_guard<std::mutex> lk(g_multi_mu);
+    std::vector<int> devs(n);
+    for (int i = 0; i < n; i++) devs[i] = i;
+    int rc = rccl_comms(devs);
+    if (rc) return rc;
+    std::vector<int32_t*> buf(n, nullptr);
+    std::vector<hipStream_t> st(n, nullptr);
+    const size_t cnt = 6 * 1000;
+    hipError_t e = hipSuccess;
+    for (int i = 0; i < n && e == hipSuccess; i++) {
+        e = hipSetDevice(i);
+        if (e == hipSuccess) e = hipMalloc((void**)&buf[i], cnt * n * 4);
+        if (e == hipSuccess) e = hipMemset(buf[i], i + 1, cnt * n * 4);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&st[i], hipStreamNonBlocking);
+    }
+    if (e != hipSuccess) rc = fail(FIC_E_HIP, "rccl selftest setup: %s", hipGetErrorString(e));
+    if (rc == FIC_OK && n >= 2) {
+        ncclResult_t r = g_rccl.GroupStart();
+        for (int i = 1; i < n && r == ncclSuccess; i++) {
+            (void)hipSetDevice(i);
+            r = g_rccl.Send(buf[i] + cnt * i, cnt, ncclInt32, 0, g_rccl.comms[i], st[i]);
+            (void)hipSetDevice(0);
+            if (r == ncclSuccess) r = g_rccl.Recv(buf[0] + cnt * i, cnt, ncclInt32, i, g_rccl.comms[0], st[0]);
+        }
+        if (r == ncclSuccess) r = g_rccl.GroupEnd();
+        if (r != ncclSuccess) rc = fail(FIC_E_HIP, "rccl selftest: %s", g_rccl.GetErrorString(r));
+        std::vector<int32_t> host(cnt * n);
+        if (rc == FIC_OK) {
+            (void)hipSetDevice(0);
+            e = hipStreamSynchronize(st[0]);
+            if (e == hipSuccess) e = hipMemcpy(host.data(), buf[0], host.size() * 4, hipMemcpyDeviceToHost);
+            if (e != hipSuccess) rc = fail(FIC_E_HIP, "rccl selftest readback: %s", hipGetErrorString(e));
+            for (int i = 0; i < n && rc == FIC_OK; i++) {
+                const int32_t want = 0x01010101 * (i + 1);
+                for (size_t k = 0; k < cnt; k++)
+                    if (host[cnt * i + k] != want) { rc = fail(FIC_E_HIP, "rccl selftest: wrong data from device %d", i); break; }
+            }
+        }
+    }
+    for (int i = 0; i < n; i++) {
+        (void)hipSetDevice(i);
+        if (st[i]) { (void)hipStreamSynchronize(st[i]); (void)hipStreamDestroy(st[i]); }
+        if (buf[i]) (void)hipFree(buf[i]);
+    }
+    return rc;
+}
+
+static void fic_release_comms_()
+{
+    std::lock_guard<std::mutex> lk(g_multi_mu);
+    if (g_rccl.lib) rccl_drop_comms();
+}
+
+int fic_encode_gray_argb_multi(const int32_t* argb, int w, int h, int B, int wK, int n_iso, int n_gpus, int32_t* idx_local,
+                               float* a, float* b, int32_t* iso, int32_t* qrows)
+{
+    if (n_gpus == 1) return encode_oneshot(nullptr, argb, w, h, B, wK, n_iso, 0, idx_local, a, b, iso, qrows);
+    return encode_multi(nullptr, argb, w, h, B, wK, n_iso, n_gpus, idx_local, a, b, iso, qrows);
+}
+
+int fic_encode_gray_u8_multi(const uint8_t* gray, int w, int h, int B, int wK, int n_iso, int n_gpus, int32_t* idx_local,
+                             float* a, float* b, int32_t* iso, int32_t* qrows)
+{
+    if (n_gpus == 1) return encode_oneshot(gray, nullptr, w, h, B, wK, n_iso, 0, idx_local, a, b, iso, qrows);
+    return encode_multi(gray, nullptr, w, h, B, wK, n_iso, n_gpus, idx_local, a, b, iso, qrows);
 }
 
 }  // extern "C"

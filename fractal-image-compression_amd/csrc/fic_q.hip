@@ -1,0 +1,664 @@
+// fic_q.hip -- the DEFAULT full-search sweep ("sweep" = 6): k_sweep_q<NK, MODE>, a matrix-core sweep whose MFMA output IS the
+// prune test, plus its fused prep kernels k_pool_q (createCodebuch FC:1015-1050 + Domainblock DB:23-29,92-115 + operand
+// fragments) and k_range_q (getRangeblock FC:588-602 + getMittelwert FC:67-73 + isometry copies + operand fragments).
+// gfx950 (MI355X / CDNA4) only, wave64.  Compile with -ffp-contract=off (FractalCompression.java = FC, Domainblock.java = DB).
+//
+// Why another sweep.  k_sweep_bf16 (fic_bf16.hip) lets the matrix cores produce the exact covariance and then spends 28 VALU
+// instructions per 32x32 tile turning it into the prune test |cov| * fl(1/sqrt(var)) > tau -- as much issue time as the four
+// MFMAs of the tile, and the two do not overlap.  Here the DOMAIN operand is normalised before it meets the matrix core:
+//     A[d][i] = f16( (d_i - dM) * fl(1/sqrt(var_d)) )      |A| <= 1, 11 significant bits
+//     B[i][c] = f16( r_i - rM )  of range copy c             exact: integers in [-255, 255]
+// so   acc = sum_i A*B  approximates  q = kovarianz / sqrt(var)  (FC:665-680 without the range constant `rem`) with
+//     |acc - q| <= E_r = 2^-10.5 * ||r - rM||_2 (+2^-16)       (derivation below; E_r is a per-range constant)
+// and the whole epilogue is  max|acc| > theta  (v_max3 tree + one compare: 9 VALU per tile, hidden beside the MFMAs).
+// Pairs that pass are queued (4 bytes each) and evaluated EXACTLY later, 64 at a time, one per lane: integer covariance by
+// v_dot4_u32_u8 from the u8 pixels, then the Java epilogue exact_error() (f64 divide, FC:677-683) and the lexicographic
+// (error, candidate) atomicMin.  The codebook bits therefore come from the same arithmetic as in every other sweep; the
+// matrix core only decides which pairs can be skipped, and it may only err on the side of evaluating too many.
+//
+// Invariant (restated for approximate values).  L(Y) = |kovarianz_Y| / sqrt(var_Y) in real arithmetic.
+// theta of a range only ever takes values  fl(fl((m - E) * (1 - 2^-17)) - E)  where m = |acc_X| of a pair X that IS evaluated
+// exactly; since L(X) >= m - E, an unflagged later pair Y (|acc_Y| <= theta) has  L(Y) <= |acc_Y| + E <= (1 - 2^-18) L(X):
+// its |r| is strictly smaller than X's, its error not smaller, and -- coming later -- it cannot win a tie (FC:627 strict <).
+// Chunk start.  The first domain tile of a pool chunk seeds theta from the tile's LARGEST |acc| (pair X*), which may have a
+// higher index than pairs it prunes; that is sound when L(X*) >= 0.26 n >= 0.25 (1 + 2^-20) rem, because then |r_X*| >= 1/4
+// and 1 - r^2 of a pair with r^2 smaller by 2^-17 relative is a strictly larger float, so the pruned pair's error is STRICTLY
+// larger and the index order is irrelevant.  Ranges whose first tile has no such pair (low contrast) evaluate the whole first
+// tile, as the older sweeps do for every range.  Candidate 0 is always evaluated (the global fallback winner, FC:613-632: every
+// pair with r^2 rounding 1 - r^2 to 1, flat blocks included, ties with it at error = rem^2 and loses on index).
+//
+// The 8 isometries at half the matrix work ("folded" mode, B = 8 / 16).  The isometries come in four pairs {k, k'} that differ
+// by the point reflection pos -> n-1-pos (0/2 = identity / rot180, 1/3 = rot90 / rot270, 4/5 = the mirrors, 6/7 = transpose /
+// anti-transpose): copy_k'[pos] = copy_k[n-1-pos].  Pairing every position with its reflection, c = copy_k centred, x = the
+// normalised domain block:
+//     q_k  = sum_pos c x = Be + Bo,   q_k' = Be - Bo,   Be = sum_{pos<n/2} (c+c')(x+x')/2,   Bo = sum_{pos<n/2} (c-c')(x-x')/2
+// so max(|q_k|, |q_k'|) = |Be| + |Bo|: per range block 4 "even" rows and 4 "odd" rows of K = n/2 instead of 8 rows of K = n --
+// half the MFMAs for the same prune test (c+c', c-c' are integers in [-510, 510]: still exact f16; the error bound is the
+// same: sum|A||D| <= 1/2 (||c+c'|| ||x+x'|| + ||c-c'|| ||x-x'||) <= ||r - rM||).  A flagged (range, pair of isometries,
+// block) evaluates both isometries exactly.
+//
+// Error bound.  w = fl(1/fl32(sqrt(var))) and x_i = fl((d_i - dM) * w) carry < 2^-21 relative error; f16 rounding 2^-11
+// relative (x_i is 0 or >= 1/2040 > 2^-14: never subnormal); products of an 8-bit and an 11-bit significand are exact in
+// f32; the NK*16-term accumulation inside the MFMAs adds at most 2^-24 * 17 NK relative to sum |A||B| <= ||r-rM|| (NK <= 16:
+// < 2^-15.9).  Total |acc - q| <= (2^-11 * 1.07) ||r - rM||_2; E_r uses 2^-10.5 (7.0e-4) plus 1.6e-5 absolute.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <math.h>
+#include <type_traits>
+#include "fic_device.h"
+#include "fic_launch.h"
+#include "fic_devfn.h"
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef float v16f __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+#define FIC_Q_LEVEL 0.99999237060546875f   // 1 - 2^-17
+#define FIC_Q_TAU_ALL 8192.0f              // > L of any pair (L <= ||r - rM|| <= 16 * 255)
+#define FIC_Q_TAU_NONE (-1.0f)             // nothing evaluated yet: every real pair of the tile is flagged
+#define FIC_Q_ECOEF 7.0e-4f                // >= 2^-10.5
+#define FIC_Q_EABS 1.6e-5f
+#define FIC_Q_QCAP 1280                    // queue entries per wave: one tile can flag at most 1024 pairs
+#define FIC_Q_QFLUSH 256                   // evaluate the queue before a tile's pushes once it holds this many
+
+__host__ __device__ constexpr int fic_q_ctw(int NK) { return NK <= 4 ? 4 : 2; }   // column tiles (x32 range copies) per wave
+
+// two floats -> packed f16 pair (round to nearest even), element 0 in the low half
+__device__ __forceinline__ int f16_pair(float lo, float hi)
+{
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    h2 v = {(_Float16)lo, (_Float16)hi};
+    return __builtin_bit_cast(int, v);
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_pool_q : one workgroup per domain tile (32 consecutive pool blocks).  createCodebuch FC:1015-1050 (block k = (c,r) at
+// scaled (c*abstand, r*abstand), pixel order rx + ry*B), Domainblock statistics (DB:92-115: int mean, exact integer
+// variance, Math.sqrt((double) var)), and the tile's A fragments for k_sweep_q.
+//   poolQ[plane][dtile][m][lane] = 8 f16 = normalised pixels [16m + 8h, +8) of block 32*dtile + (lane&31), h = lane>>5.
+//   dflat[plane][dtile] = 1 (u32) when all 32 blocks are flat or beyond N_d (their fragments are zero).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_pool_q(const uint8_t* __restrict__ scaled, uint8_t* __restrict__ pool_pix,
+                                                FicDomStat* __restrict__ pool_st, uint32_t* __restrict__ pool_var,
+                                                double* __restrict__ pool_s64, v4i* __restrict__ poolQ,
+                                                uint32_t* __restrict__ dflat, FicGeom g, int ndtiles_alloc, int folded)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t pix[32][256 + 16];
+    __shared__ int s_sum[32][16], s_sq[32][16];
+    __shared__ float s_w[32];
+    __shared__ int s_mean[32];
+    __shared__ int s_nonflat;
+    const int B = g.B, n = g.n, NK = n / 16;
+    const int dtile = blockIdx.x, plane = blockIdx.y;
+    if (threadIdx.x == 0) s_nonflat = 0;
+    // (a) rows of the tile's blocks: thread = (block i, row ry)
+    for (int t = threadIdx.x; t < 32 * B; t += 256) {
+        const int i = t / B, ry = t % B;
+        const int d = dtile * 32 + i;
+        int sum = 0, sq = 0;
+        uint8_t* dst = &pix[i][ry * B];
+        if (d < g.Nd) {
+            const int c = d % g.Dw, r = d / g.Dw;
+            const uint8_t* src = scaled + (size_t)plane * g.Ws * g.Hs + (size_t)(r * g.abstand + ry) * g.Ws + c * g.abstand;
+            for (int rx = 0; rx < B; rx++) {
+                const int v = src[rx];
+                dst[rx] = (uint8_t)v;
+                sum += v;
+                sq += v * v;
+            }
+            uint8_t* out = pool_pix + ((size_t)plane * g.Nd_pad + d) * n + ry * B;
+            if (B == 4) *(uint32_t*)out = *(const uint32_t*)dst;
+            else if (B == 8) *(uint2*)out = *(const uint2*)dst;
+            else *(uint4*)out = *(const uint4*)dst;
+        } else {
+            for (int rx = 0; rx < B; rx++) dst[rx] = 0;
+        }
+        s_sum[i][ry] = sum;
+        s_sq[i][ry] = sq;
+    }
+    __syncthreads();
+    // (b) per-block statistics
+    if (threadIdx.x < 32) {
+        const int i = threadIdx.x, d = dtile * 32 + i;
+        int S = 0, Q = 0;
+        for (int t = 0; t < B; t++) { S += s_sum[i][t]; Q += s_sq[i][t]; }
+        const int m = S >> g.lgn;                                  // mittelWert = S / n (DB:97)
+        const int var = Q - 2 * m * S + n * m * m;                 // sum (d - m)^2, exact integer < 2^24 (DB:110-111)
+        const double s64 = __dsqrt_rn((double)var);                // Math.sqrt((double) variance), FC:677,680
+        const float s32 = (float)s64;
+        float w = 0.0f;
+        if (d < g.Nd) {
+            const size_t o = (size_t)plane * g.Nd_pad + d;
+            FicDomStat st;
+            st.sum = (uint32_t)S;
+            st.s32 = s32;
+            pool_st[o] = st;
+            pool_var[o] = (uint32_t)var;
+            pool_s64[o] = s64;
+            if (var != 0) { w = __fdiv_rn(1.0f, s32); atomicOr(&s_nonflat, 1); }
+        }
+        s_w[i] = w;
+        s_mean[i] = m;
+    }
+    __syncthreads();
+    // (c) fragments
+    for (int t = threadIdx.x; t < NK * 64; t += 256) {
+        const int lane = t & 63, m = t >> 6;
+        const int i = lane & 31, h = lane >> 5;
+        const float w = s_w[i];
+        const int dM = s_mean[i];
+        v4i v;
+        if (!folded) {
+            const uint8_t* p = &pix[i][16 * m + 8 * h];
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+                v[u] = f16_pair(__fmul_rn((float)((int)p[2 * u] - dM), w), __fmul_rn((float)((int)p[2 * u + 1] - dM), w));
+        } else {
+            // steps m < NK/2: even part (x + x')/2 of positions [16m + 8h, +8), x' at n-1-pos; steps m >= NK/2: odd part (x - x')/2
+            const bool odd = m >= NK / 2;
+            const int p0 = 16 * (odd ? m - NK / 2 : m) + 8 * h;
+            float f[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int a = pix[i][p0 + u], b = pix[i][n - 1 - (p0 + u)];
+                f[u] = __fmul_rn(__fmul_rn((float)(odd ? a - b : a + b - 2 * dM), w), 0.5f);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) v[u] = f16_pair(f[2 * u], f[2 * u + 1]);
+        }
+        poolQ[((size_t)plane * ndtiles_alloc + dtile) * NK * 64 + t] = v;
+    }
+    if (threadIdx.x == 0) dflat[(size_t)plane * ndtiles_alloc + dtile] = s_nonflat ? 0u : 1u;
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_range_q : one workgroup per 64 range blocks.  getRangeblock FC:588-602 (R-channel bytes, row-major), getMittelwert
+// FC:67-73 (rM = sum / n, int), rem = sum - n*rM (= varianzRange after the loop at FC:665-672), the error bound E_r, the
+// search key reset, the u8 isometry copies for the exact path, and the B fragments for k_sweep_q.
+//   copy_k[pos] = r[iso_source(iso_inverse(k), pos)]  so that  dot(copy_k, d) == dot(r, iso_k(d))   
+//   column rr of the sweep: mode 0 (1 isometry): range rr; mode 1 (8 isometries, direct): range rr >> 3, copy rr & 7;
+//   mode 2 (8 isometries, folded): range rr >> 2, isometry pair rr & 3 = {0,2}, {1,3}, {4,5}, {6,7}.
+//   rngQ[plane][ctile][m][lane] = 8 f16 of column 32*ctile + (lane&31), h = lane>>5: centred pixels [16m + 8h, +8) of the
+//   copy; folded: steps m < NK/2 the even part c + c' of positions [16m + 8h, +8), steps m >= NK/2 the odd part c - c'.
+//   rng_u8[plane][j][k][n] bytes.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_range_q(const uint8_t* __restrict__ gray, FicRngStat* __restrict__ rng_st,
+                                                 float* __restrict__ rngE, unsigned long long* __restrict__ key,
+                                                 uint8_t* __restrict__ rng_u8, v4i* __restrict__ rngQ, FicGeom g,
+                                                 int nct_alloc, int grp0, int mode)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t blk[64 * (256 + 4)];
+    __shared__ int s_rM[64];
+    const int plane = blockIdx.y;
+    const int grp = grp0 + blockIdx.x;
+    const int B = g.B, n = g.n, DW = g.DW, NK = n / 16, n_iso = g.n_iso;
+    const int stride = n + 4;
+    const int j0 = grp * 64;
+    const uint8_t* img = gray + (size_t)plane * g.W * g.H;
+    for (int i = threadIdx.x; i < 64 * DW; i += 256) {         // DW words per block
+        const int l = i / DW, wd = i % DW;
+        const int j = j0 + l;
+        uint32_t v = 0;
+        if (j < g.Nr) {
+            const int pos = wd * 4;
+            const uint8_t* p = img + (size_t)((j / g.Rw) * B + pos / B) * g.W + (j % g.Rw) * B + pos % B;
+            v = *(const uint32_t*)p;                           // B, W multiples of 4: aligned
+        }
+        *(uint32_t*)&blk[l * stride + wd * 4] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const int j = j0 + threadIdx.x;
+        const uint8_t* b = blk + threadIdx.x * stride;
+        int S = 0;
+        for (int i = 0; i < n; i++) S += b[i];
+        const int rM = S >> g.lgn;
+        int ss = 0;
+        for (int i = 0; i < n; i++) { const int a = (int)b[i] - rM; ss += a * a; }
+        s_rM[threadIdx.x] = rM;
+        if (j < g.Nr_pad) {
+            const size_t o = (size_t)plane * g.Nr_pad + j;
+            FicRngStat st;
+            st.rM = j < g.Nr ? rM : 0;
+            st.rem = j < g.Nr ? S - (rM << g.lgn) : 0;
+            rng_st[o] = st;
+            rngE[o] = __fadd_rn(__fmul_rn(__fsqrt_rn((float)ss), FIC_Q_ECOEF), FIC_Q_EABS);
+            key[o] = FIC_KEY_NONE;
+        }
+    }
+    __syncthreads();
+    // u8 isometry copies: thread = (range l, copy k, 4 pixels)
+    for (int o = threadIdx.x; o < 64 * n_iso * DW; o += 256) {
+        const int dw = o % DW, k = (o / DW) % n_iso, l = o / (DW * n_iso);
+        const int j = j0 + l;
+        if (j >= g.Nr) continue;
+        const int ki = iso_inverse(k);
+        const uint8_t* b = blk + l * stride;
+        uint32_t w = 0;
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            const int pos = dw * 4 + t;
+            w |= (uint32_t)b[iso_source(ki, B, pos % B, pos / B)] << (8 * t);
+        }
+        ((uint32_t*)rng_u8)[(((size_t)plane * g.Nr_pad + j) * n_iso + k) * DW + dw] = w;
+    }
+    // fragments: thread = (column tile, m, lane)
+    const int cpr = mode == 0 ? 1 : (mode == 1 ? 8 : 4);       // columns per range block
+    const int cols = 64 * cpr;                                 // columns of this workgroup
+    const int ct0 = (j0 * cpr) / 32;
+    for (int t = threadIdx.x; t < (cols / 32) * NK * 64; t += 256) {
+        const int lane = t & 63, m = (t >> 6) % NK, ctl = (t >> 6) / NK;
+        const int col = ctl * 32 + (lane & 31), h = lane >> 5;
+        const int l = col / cpr, c = col % cpr;
+        const int k = mode == 2 ? (c == 0 ? 0 : (c == 1 ? 1 : (c == 2 ? 4 : 6))) : c;   // folded: the pair's first isometry
+        const int ki = iso_inverse(k);
+        const uint8_t* b = blk + l * stride;
+        const int rM = s_rM[l];
+        const bool real = j0 + l < g.Nr;
+        int a[8];
+        if (mode != 2) {
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int p0 = 16 * m + 8 * h + u;
+                a[u] = (int)b[iso_source(ki, B, p0 % B, p0 / B)] - rM;
+            }
+        } else {
+            const bool odd = m >= NK / 2;
+            const int q0 = 16 * (odd ? m - NK / 2 : m) + 8 * h;
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int p0 = q0 + u, p1 = n - 1 - p0;
+                const int c0 = b[iso_source(ki, B, p0 % B, p0 / B)], c1 = b[iso_source(ki, B, p1 % B, p1 / B)];
+                a[u] = odd ? c0 - c1 : c0 + c1 - 2 * rM;
+            }
+        }
+        v4i v;
+#pragma unroll
+        for (int u = 0; u < 4; u++) v[u] = real ? f16_pair((float)a[2 * u], (float)a[2 * u + 1]) : 0;
+        if (ct0 + ctl < nct_alloc) rngQ[((size_t)plane * nct_alloc + ct0 + ctl) * NK * 64 + (size_t)m * 64 + lane] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_sweep_q<NK, MODE>      MODE 0: 1 isometry (the reference algorithm); 1: 8 isometries, one column per copy (B = 4);
+//                          2: 8 isometries folded by the point reflection (B = 8 / 16; see the header)
+//   rows (A) = 32 consecutive domain blocks, streamed from L2/HBM (three VGPR buffers in rotation);
+//   cols (B) = 32 range columns (a copy, or in MODE 2 an isometry pair); a wave keeps the fragments of its CTW column tiles
+//              in VGPRs for the whole sweep, a workgroup = 4 waves = 4*CTW column tiles.
+//   acc[e] of lane (col = lane&31, half = lane>>5) belongs to (column col, domain block 32*dt + (e&3) + 8(e>>2) + 4*half);
+//   MODE 2 has two accumulators per tile (even / odd part, NK/2 MFMAs each) and tests |even| + |odd|.
+//   theta of the lane's range sits in one VGPR per column tile; the lanes that share a range (two halves x the range's
+//   columns) exchange raised values through LDS (ds_max on an order-preserving integer image) when something is flagged.
+//   The next tile's MFMAs are issued interleaved with the current tile's epilogue (sched_group_barrier).
+// ---------------------------------------------------------------------------------------------
+struct QArgs {
+    const v4i* poolQ;                // [plane][ndtiles_alloc][NK][64]
+    const uint32_t* dflat;           // [plane][ndtiles_alloc]
+    const uint8_t* pool_pix;         // [plane][Nd_pad][n]
+    const FicDomStat* pool_st;
+    const double* pool_s64;
+    const v4i* rngQ;                 // [plane][nct_alloc][NK][64]
+    const uint8_t* rng_u8;           // [plane][Nr_pad][n_iso][n]
+    const FicRngStat* rng_st;
+    const float* rngE;
+    unsigned long long* key;
+    unsigned long long* stats;       // optional [4]: tile epilogues, tiles with flagged pairs, queued entries, waves
+    int Nd, Nd_pad, Nr, Nr_pad, n, lgn;
+    int ndtiles, ndtiles_alloc, nct_alloc;
+    int ct_begin, ct_end;            // column tiles (x32 columns) of this shard
+    int nctg;                        // column-tile groups (workgroups) in this launch
+    int tiles_per_chunk, nchunks, planes;
+};
+
+__device__ __forceinline__ v16f mfma_f16(v4i a, v4i b, v16f c)
+{
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ float max16_abs(const v16f& a)
+{
+    const float m0 = fmaxf(fmaxf(fabsf(a[0]), fabsf(a[1])), fabsf(a[2]));
+    const float m1 = fmaxf(fmaxf(fabsf(a[3]), fabsf(a[4])), fabsf(a[5]));
+    const float m2 = fmaxf(fmaxf(fabsf(a[6]), fabsf(a[7])), fabsf(a[8]));
+    const float m3 = fmaxf(fmaxf(fabsf(a[9]), fabsf(a[10])), fabsf(a[11]));
+    const float m4 = fmaxf(fmaxf(fabsf(a[12]), fabsf(a[13])), fabsf(a[14]));
+    return fmaxf(fmaxf(fmaxf(m0, m1), m2), fmaxf(fmaxf(m3, m4), fabsf(a[15])));
+}
+// MODE 2: |even| + |odd| per element, then the maximum
+__device__ __forceinline__ float max16_sum(const v16f& a, const v16f& b)
+{
+    float v[16];
+#pragma unroll
+    for (int e = 0; e < 16; e++) v[e] = fabsf(a[e]) + fabsf(b[e]);
+    const float m0 = fmaxf(fmaxf(v[0], v[1]), v[2]), m1 = fmaxf(fmaxf(v[3], v[4]), v[5]), m2 = fmaxf(fmaxf(v[6], v[7]), v[8]);
+    const float m3 = fmaxf(fmaxf(v[9], v[10]), v[11]), m4 = fmaxf(fmaxf(v[12], v[13]), v[14]);
+    return fmaxf(fmaxf(fmaxf(m0, m1), m2), fmaxf(fmaxf(m3, m4), v[15]));
+}
+
+template <int MODE> struct QMode {
+    static constexpr int CSHIFT = MODE == 0 ? 0 : (MODE == 1 ? 3 : 2);   // log2(columns per range block)
+    static constexpr int NISO = MODE == 0 ? 1 : 8;
+};
+// first isometry of column sub-index c (MODE 2: of the pair {0,2}, {1,3}, {4,5}, {6,7})
+template <int MODE> __device__ __forceinline__ int q_col_iso(int c) { return MODE == 2 ? (c == 0 ? 0 : (c == 1 ? 1 : (c == 2 ? 4 : 6))) : c; }
+
+// Exact evaluation of the queued entries, one per lane: kovarianz = sum r*d - rM*sum(d) - dM*rem (exact integers), then
+// getErrorVarianceCovariance FC:674-683 and the strict-'<' scan of FC:619-632 as a lexicographic atomicMin.  A MODE 2 entry
+// is an isometry pair: both copies are evaluated against the one domain block.
+// (Inlined: as a real call it costs the kernel 50 more VGPRs for the calling convention, i.e. a wave per SIMD.)
+template <int NK, int MODE>
+__device__ __forceinline__ void q_flush(const QArgs& A, const uint32_t* myq, int qn, int plane, int ctw0, int lane)
+{
+    constexpr int NISO = QMode<MODE>::NISO, CSHIFT = QMode<MODE>::CSHIFT;
+    const FicRngStat* rst = A.rng_st + (size_t)plane * A.Nr_pad;
+    const double* p64 = A.pool_s64 + (size_t)plane * A.Nd_pad;
+    const FicDomStat* pst = A.pool_st + (size_t)plane * A.Nd_pad;
+    unsigned long long* keyp = A.key + (size_t)plane * A.Nr_pad;
+    for (int base = 0; base < qn; base += 64) {
+        const int i = base + lane;
+        if (i < qn) {
+            const uint32_t ent = myq[i];
+            const uint32_t d = ent & 0x00FFFFFFu;
+            const int col = ctw0 * 32 + (int)(ent >> 24);
+            const int j = col >> CSHIFT, k = q_col_iso<MODE>(col & ((1 << CSHIFT) - 1));
+            const int k2 = k == 0 ? 2 : (k == 1 ? 3 : k + 1);                       // MODE 2: the pair's second isometry
+            const uint4* dp = (const uint4*)(A.pool_pix + ((size_t)plane * A.Nd_pad + d) * A.n);
+            const uint4* rp = (const uint4*)(A.rng_u8 + (((size_t)plane * A.Nr_pad + j) * NISO + k) * A.n);
+            const uint4* rp2 = (const uint4*)(A.rng_u8 + (((size_t)plane * A.Nr_pad + j) * NISO + k2) * A.n);
+            const FicRngStat rs = rst[j];
+            const int Sd = (int)pst[d].sum;
+            const double s64 = p64[d];
+            uint32_t s = 0, s2 = 0;
+#pragma unroll
+            for (int v = 0; v < NK; v++) {
+                const uint4 x = dp[v], y = rp[v];
+                s = __builtin_amdgcn_udot4(x.x, y.x, s, false);
+                s = __builtin_amdgcn_udot4(x.y, y.y, s, false);
+                s = __builtin_amdgcn_udot4(x.z, y.z, s, false);
+                s = __builtin_amdgcn_udot4(x.w, y.w, s, false);
+                if constexpr (MODE == 2) {
+                    const uint4 z = rp2[v];
+                    s2 = __builtin_amdgcn_udot4(x.x, z.x, s2, false);
+                    s2 = __builtin_amdgcn_udot4(x.y, z.y, s2, false);
+                    s2 = __builtin_amdgcn_udot4(x.z, z.z, s2, false);
+                    s2 = __builtin_amdgcn_udot4(x.w, z.w, s2, false);
+                }
+            }
+            const int base_c = rs.rM * Sd + (Sd >> A.lgn) * rs.rem;
+            const float err = exact_error((int)s - base_c, rs.rem, s64);
+            unsigned long long best = ((unsigned long long)f32_orderable(err) << 32) | (d * (uint32_t)NISO + (uint32_t)k);
+            if constexpr (MODE == 2) {
+                const float err2 = exact_error((int)s2 - base_c, rs.rem, s64);
+                const unsigned long long b2 = ((unsigned long long)f32_orderable(err2) << 32) | (d * (uint32_t)NISO + (uint32_t)k2);
+                best = b2 < best ? b2 : best;
+            }
+            atomicMin(&keyp[j], best);
+        }
+    }
+}
+
+template <int NK, int MODE>
+__global__ __launch_bounds__(256) void k_sweep_q(QArgs A)
+{
+    constexpr int CTW = fic_q_ctw(NK), CT = 4 * CTW;
+    constexpr int CSHIFT = QMode<MODE>::CSHIFT;
+    constexpr bool FOLD = MODE == 2;
+    constexpr int NKA = FOLD ? NK / 2 : NK;                  // MFMA steps per accumulator
+    __shared__ uint32_t sTau[4][CTW * 32];             // per wave, per range slot: theta as an order-preserving integer
+    __shared__ uint32_t sMax[4][CTW * 32];             // per wave, per range slot: largest test value of the chunk's first tile
+    __shared__ uint32_t sQ[4][FIC_Q_QCAP];             // per wave: domain block | column-in-wave << 24
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int combo_, gx_;
+    xcd_decode(blockIdx.x, A.nchunks * A.planes, A.nctg, combo_, gx_);
+    const int plane = combo_ / A.nchunks;
+    const int chunk = combo_ % A.nchunks;
+    const int ctw0 = A.ct_begin + gx_ * CT + wave * CTW;     // first column tile of this wave
+    const int dt0 = chunk * A.tiles_per_chunk;
+    int dt1 = dt0 + A.tiles_per_chunk;
+    if (dt1 > A.ndtiles) dt1 = A.ndtiles;
+    if (dt0 >= dt1 || ctw0 >= A.ct_end) return;              // (no barrier in this kernel: waves are independent)
+    int nci = A.ct_end - ctw0;                               // column tiles this wave really owns (wave-uniform)
+    if (nci > CTW) nci = CTW;
+
+    const int jcol = lane & 31, half = lane >> 5;
+    const FicRngStat* rst = A.rng_st + (size_t)plane * A.Nr_pad;
+    uint32_t* const myTau = sTau[wave];
+    uint32_t* const myMax = sMax[wave];
+    uint32_t* const myq = sQ[wave];
+
+    v4i rb[CTW][NK];
+    {
+        const v4i* rp = A.rngQ + ((size_t)plane * A.nct_alloc + ctw0) * NK * 64 + lane;
+#pragma unroll
+        for (int ci = 0; ci < CTW; ci++)
+#pragma unroll
+            for (int m = 0; m < NK; m++) rb[ci][m] = rp[(ci * NK + m) * 64];
+    }
+    // per lane and column tile: the range behind the column, its theta, its error bound
+    float tau[CTW], E[CTW];
+    uint32_t okbits = 0, raise = 0;                          // bit ci: the column's range exists / may raise theta (rem != 0)
+#pragma unroll
+    for (int ci = 0; ci < CTW; ci++) {
+        const int col = (ctw0 + ci) * 32 + jcol;
+        const int j = col >> CSHIFT;
+        const bool ok = j < A.Nr && ci < nci;
+        const int rem = ok ? rst[j].rem : 0;
+        E[ci] = ok ? A.rngE[(size_t)plane * A.Nr_pad + j] : 0.0f;
+        // rem == 0: error 0 for every block (FC:677) -> only candidate 0 can win; padding: never flagged
+        tau[ci] = (ok && rem != 0) ? FIC_Q_TAU_NONE : FIC_Q_TAU_ALL;
+        okbits |= ok ? 1u << ci : 0u;
+        raise |= (ok && rem != 0) ? 1u << ci : 0u;
+        const int slot = (ci * 32 + jcol) >> CSHIFT;
+        myTau[slot] = f32_orderable(tau[ci]);                // (lanes sharing a slot write the same value)
+        myMax[slot] = 0u;
+    }
+
+    const v4i* pa = A.poolQ + (size_t)plane * A.ndtiles_alloc * NK * 64 + lane;
+    // flat-tile flags through the scalar cache (wave-uniform address; a vector load here would make the slow path wait for
+    // the prefetched fragment loads as well: s_waitcnt vmcnt(0))
+    const uint32_t AS4* pflat = (const uint32_t AS4*)(uintptr_t)(A.dflat + (size_t)plane * A.ndtiles_alloc);
+    const v16f zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    int qn = 0;                                              // queued entries (wave-uniform)
+    unsigned st_slow = 0, st_pairs = 0;                      // instrumentation (wave-uniform; reported when A.stats is set)
+
+    auto flush = [&]() __attribute__((always_inline)) {
+        q_flush<NK, MODE>(A, myq, qn, plane, ctw0, lane);
+        qn = 0;
+    };
+    // test value of element e: |q| (MODE 0/1) or |even| + |odd| = the larger |q| of the isometry pair (MODE 2)
+    auto val = [&](const v16f& acc, const v16f& acc2, int e) __attribute__((always_inline)) {
+        return FOLD ? fabsf(acc[e]) + fabsf(acc2[e]) : fabsf(acc[e]);
+    };
+    // a tile with flagged entries: queue them, raise theta.  FIRST: the chunk's first tile (theta was just seeded).
+    auto flagged_tile = [&](const v16f& acc, const v16f& acc2, float mx, int ci, int dt, bool first) __attribute__((always_inline)) {
+        // only zeros flagged (theta still "none"): an all-flat tile seen before anything was evaluated needs nothing
+        if (!first && __builtin_amdgcn_ballot_w64(mx > 0.0f) == 0 && pflat[dt] != 0u) return;
+        if (qn > FIC_Q_QFLUSH) flush();
+        st_slow++;
+        const bool ok = (okbits >> ci) & 1u;
+        const int colw = ci * 32 + jcol;                     // column in wave
+        const int slot = colw >> CSHIFT;
+        // candidate 0 = (block 0, copy 0): always evaluated (MODE 2: with its partner, copy 2)
+        const bool cand0 = first && dt == 0 && half == 0 && ok && (jcol & ((1 << CSHIFT) - 1)) == 0;
+        float mp = -1.0f;                                    // largest flagged test value on this lane
+#pragma unroll
+        for (int e = 0; e < 16; e++) {
+            const int d = dt * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
+            const float ve = val(acc, acc2, e);
+            const bool pe = (ok && d < A.Nd && ve > tau[ci]) || (e == 0 && cand0);
+            const unsigned long long be = __builtin_amdgcn_ballot_w64(pe);
+            if (be == 0) continue;
+            const int idx = qn + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(be >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)be, 0u));
+            if (pe) {
+                myq[idx] = (uint32_t)d | ((uint32_t)colw << 24);
+                mp = fmaxf(mp, ve);
+            }
+            qn += __builtin_popcountll(be);
+            st_pairs += (unsigned)__builtin_popcountll(be);
+        }
+        if (((raise >> ci) & 1u) && mp >= 0.0f) {
+            const float lb = __fsub_rn(__fmul_rn(__fsub_rn(mp, E[ci]), FIC_Q_LEVEL), E[ci]);
+            atomicMax(&myTau[slot], f32_orderable(lb));
+        }
+        tau[ci] = f32_from_orderable(myTau[slot]);           // own update and those of the lanes sharing the range
+    };
+    // the chunk's first tile: seed theta from the tile's largest test value per range (see the header), then flag as usual
+    auto first_tile = [&](const v16f& acc, const v16f& acc2, int ci, int dt) __attribute__((always_inline)) {
+        const bool ok = (okbits >> ci) & 1u;
+        const int colw = ci * 32 + jcol;
+        const int slot = colw >> CSHIFT;
+        const float mx = FOLD ? max16_sum(acc, acc2) : max16_abs(acc);      // rows beyond N_d are zero fragments: value 0
+        if (ok) atomicMax(&myMax[slot], __float_as_uint(mx));   // >= 0: integer order == float order
+        const float lo = __fsub_rn(__uint_as_float(myMax[slot]), E[ci]);
+        if (((raise >> ci) & 1u) && lo >= 0.26f * (float)A.n) {
+            const float t0 = __fsub_rn(__fmul_rn(lo, FIC_Q_LEVEL), E[ci]);
+            tau[ci] = fmaxf(tau[ci], t0);
+            myTau[slot] = f32_orderable(tau[ci]);            // every lane of the slot computes the same value
+        }
+        flagged_tile(acc, acc2, mx, ci, dt, true);
+    };
+    // accumulator(s) of one 32x32 tile: FOLD: even part from steps [0, NK/2), odd part from steps [NK/2, NK)
+    auto tile_mfma = [&](const v4i (&at)[NK], const v4i (&bt)[NK], v16f& acc, v16f& acc2) __attribute__((always_inline)) {
+        acc = zero;
+#pragma unroll
+        for (int m = 0; m < NKA; m++) acc = mfma_f16(at[m], bt[m], acc);
+        if constexpr (FOLD) {
+            acc2 = zero;
+#pragma unroll
+            for (int m = NKA; m < NK; m++) acc2 = mfma_f16(at[m], bt[m], acc2);
+        }
+    };
+
+    // Fragment buffers in rotation.  PF = 2: a step computes on `ac`, finishes with the first tile of `an` (loaded during the
+    // previous step) and starts the loads of `a2n`, two domain tiles ahead (~1.75 steps to land); PF = 1 (where registers
+    // are short): two buffers, the next tile's loads start at the top of the step.
+    constexpr int PF = (NK == 4 && !FOLD) ? 2 : 1;
+    v4i a0[NK], a1[NK], a2[PF == 2 ? NK : 1];
+#pragma unroll
+    for (int m = 0; m < NK; m++) a0[m] = pa[((size_t)dt0 * NK + m) * 64];
+    if constexpr (PF == 2) {
+#pragma unroll
+        for (int m = 0; m < NK; m++) a1[m] = pa[((size_t)(dt0 + 1) * NK + m) * 64];
+    }
+    v16f acc, acc2 = zero;
+    tile_mfma(a0, rb[0], acc, acc2);
+
+    // one domain tile (the fragment store has two spare tiles for the prefetch); `ld` receives tile dt + PF
+    auto step = [&](auto forced, int dt, const v4i (&ac)[NK], const v4i (&an)[NK], v4i (&ld)[NK]) __attribute__((always_inline)) {
+        constexpr bool FORCE = decltype(forced)::value;
+#pragma unroll
+        for (int m = 0; m < NK; m++) ld[m] = pa[((size_t)(dt + PF) * NK + m) * 64];
+#pragma unroll
+        for (int ci = 0; ci < CTW; ci++) {
+            // the next tile's MFMAs: column tile ci+1 of this domain tile, or column tile 0 of the next domain tile
+            v16f nacc, nacc2 = zero;
+            if (ci + 1 < CTW) tile_mfma(ac, rb[ci + 1], nacc, nacc2);
+            else tile_mfma(an, rb[0], nacc, nacc2);
+            if constexpr (FORCE) {
+                if (ci < nci) first_tile(acc, acc2, ci, dt);
+            } else {
+                const float mx = FOLD ? max16_sum(acc, acc2) : max16_abs(acc);
+                const bool hit = mx > tau[ci];
+                if constexpr (NK == 4 && !FOLD) {
+                    // M M v v v M v v v M v v v v v: the epilogue reads a tile whose last MFMA was issued >= 64 cycles ago
+                    __builtin_amdgcn_sched_group_barrier(0x8, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x2, 3, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x2, 3, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x2, 3, 0);
+                } else if constexpr (NK == 4 && FOLD) {
+                    // 4 MFMAs (two 2-step accumulators), 16 adds + 8 max + compare: M M v*8 M v*8 M v*9
+                    __builtin_amdgcn_sched_group_barrier(0x8, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x2, 8, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x2, 8, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x2, 9, 0);
+                }
+                if (__builtin_expect(__builtin_amdgcn_ballot_w64(hit) != 0, 0)) flagged_tile(acc, acc2, mx, ci, dt, false);
+            }
+            acc = nacc;
+            if constexpr (FOLD) acc2 = nacc2;
+        }
+    };
+    int dt = dt0;
+    if constexpr (PF == 2) {
+        step(std::true_type{}, dt, a0, a1, a2);
+        dt++;
+        for (; dt + 2 < dt1; dt += 3) {
+            step(std::false_type{}, dt, a1, a2, a0);
+            step(std::false_type{}, dt + 1, a2, a0, a1);
+            step(std::false_type{}, dt + 2, a0, a1, a2);
+        }
+        if (dt < dt1) {
+            step(std::false_type{}, dt, a1, a2, a0);
+            if (dt + 1 < dt1) step(std::false_type{}, dt + 1, a2, a0, a1);
+        }
+    } else {
+        step(std::true_type{}, dt, a0, a1, a1);
+        dt++;
+        for (; dt + 1 < dt1; dt += 2) {
+            step(std::false_type{}, dt, a1, a0, a0);
+            step(std::false_type{}, dt + 1, a0, a1, a1);
+        }
+        if (dt < dt1) step(std::false_type{}, dt, a1, a0, a0);
+    }
+    flush();
+    if (A.stats && lane == 0) {
+        atomicAdd(&A.stats[0], (unsigned long long)(dt1 - dt0) * (unsigned)nci);
+        atomicAdd(&A.stats[1], (unsigned long long)st_slow);
+        atomicAdd(&A.stats[2], (unsigned long long)st_pairs);
+        atomicAdd(&A.stats[3], 1ull);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host-side launchers
+// ---------------------------------------------------------------------------------------------
+int fic_q_ct(int B) { return 4 * fic_q_ctw(B * B / 16); }       // column tiles (x32 columns) per workgroup
+// 0: 1 isometry; 1: 8 isometries, one column per copy; 2: 8 isometries folded into 4 columns per range block
+int fic_q_mode(int B, int n_iso) { return n_iso == 1 ? 0 : (B == 4 ? 1 : 2); }
+int fic_q_cols_per_range(int B, int n_iso) { const int m = fic_q_mode(B, n_iso); return m == 0 ? 1 : (m == 1 ? 8 : 4); }
+
+int fic_launch_q_prep(const FicBuffers& b, void* poolQ, void* dflat, void* rngQ, void* rngE, void* rng_u8, const FicGeom& g,
+                      int ndtiles_alloc, int nct_alloc, int grp0, int ngrp, hipStream_t s)
+{
+    const int mode = fic_q_mode(g.B, g.n_iso);
+    hipLaunchKernelGGL(k_pool_q, dim3(ndtiles_alloc, g.planes), dim3(256), 0, s, (const uint8_t*)b.scaled, b.pool_pix,
+                       b.pool_st, b.pool_var, b.pool_s64, (v4i*)poolQ, (uint32_t*)dflat, g, ndtiles_alloc, mode == 2 ? 1 : 0);
+    FIC_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_range_q, dim3(ngrp, g.planes), dim3(256), 0, s, (const uint8_t*)b.gray, b.rng_st, (float*)rngE, b.key,
+                       (uint8_t*)rng_u8, (v4i*)rngQ, g, nct_alloc, grp0, mode);
+    FIC_LAUNCH_CHECK();
+    return 0;
+}
+
+int fic_launch_sweep_q(const FicBuffers& b, const void* poolQ, const void* dflat, const void* rngQ, const void* rngE,
+                       const void* rng_u8, const FicGeom& g, int ct_begin, int ct_end, int ndtiles, int ndtiles_alloc,
+                       int nct_alloc, int tiles_per_chunk, int nchunks, hipStream_t s, unsigned long long* stats)
+{
+    QArgs A;
+    A.stats = stats;
+    A.poolQ = (const v4i*)poolQ; A.dflat = (const uint32_t*)dflat; A.pool_pix = b.pool_pix; A.pool_st = b.pool_st;
+    A.pool_s64 = b.pool_s64; A.rngQ = (const v4i*)rngQ; A.rng_u8 = (const uint8_t*)rng_u8; A.rng_st = b.rng_st;
+    A.rngE = (const float*)rngE; A.key = b.key;
+    A.Nd = g.Nd; A.Nd_pad = g.Nd_pad; A.Nr = g.Nr; A.Nr_pad = g.Nr_pad; A.n = g.n; A.lgn = g.lgn;
+    A.ndtiles = ndtiles; A.ndtiles_alloc = ndtiles_alloc; A.nct_alloc = nct_alloc;
+    A.ct_begin = ct_begin; A.ct_end = ct_end; A.tiles_per_chunk = tiles_per_chunk; A.nchunks = nchunks;
+    const int CT = fic_q_ct(g.B);
+    A.nctg = (ct_end - ct_begin + CT - 1) / CT;
+    A.planes = g.planes;
+    if (ct_begin + A.nctg * CT > nct_alloc || g.Nd >= (1 << 24) || ndtiles + 2 > ndtiles_alloc) return (int)hipErrorInvalidValue;
+    dim3 grid((unsigned)(nchunks * g.planes) * (unsigned)A.nctg), block(256);
+    const int mode = fic_q_mode(g.B, g.n_iso);
+    if (g.B == 4 && mode == 0) hipLaunchKernelGGL((k_sweep_q<1, 0>), grid, block, 0, s, A);
+    else if (g.B == 4 && mode == 1) hipLaunchKernelGGL((k_sweep_q<1, 1>), grid, block, 0, s, A);
+    else if (g.B == 8 && mode == 0) hipLaunchKernelGGL((k_sweep_q<4, 0>), grid, block, 0, s, A);
+    else if (g.B == 8 && mode == 2) hipLaunchKernelGGL((k_sweep_q<4, 2>), grid, block, 0, s, A);
+    else if (g.B == 16 && mode == 0) hipLaunchKernelGGL((k_sweep_q<16, 0>), grid, block, 0, s, A);
+    else if (g.B == 16 && mode == 2) hipLaunchKernelGGL((k_sweep_q<16, 2>), grid, block, 0, s, A);
+    else return (int)hipErrorInvalidValue;
+    FIC_LAUNCH_CHECK();
+    return 0;
+}

@@ -127,6 +127,12 @@ class Encoder:
         capi.check(capi.lib().fic_ctx_sweep_time(self._h, C.byref(ms), C.byref(n), 1 if reset else 0))
         return ms.value, n.value
 
+    def sweep_stats(self, reset=True):
+        """k_sweep_q counters (after set_option("sweep_stats", 1)): tile epilogues, flagged tiles, exact pairs, waves."""
+        v = (C.c_uint64 * 4)()
+        capi.check(capi.lib().fic_ctx_sweep_stats(self._h, v, 1 if reset else 0))
+        return dict(zip(["tiles", "flagged_tiles", "exact_pairs", "waves"], [int(x) for x in v]))
+
     def info(self):
         v = (C.c_int * 10)()
         capi.check(capi.lib().fic_ctx_info(self._h, v))

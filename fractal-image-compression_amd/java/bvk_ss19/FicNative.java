@@ -27,6 +27,18 @@ public final class FicNative {
                                          int device, float[] out3N, int[] quant3N);
 
     /**
+     * The same search sharded over the first {@code nGpus} HIP devices of the node: still one synchronous call on the
+     * calling thread (FractalCompression.encode, FractalCompression.java:54-59, is one call on the JavaFX thread); range
+     * blocks are independent (FractalCompression.java:125-159), the codebook rows are gathered inside the library with
+     * RCCL.  The result does not depend on nGpus.
+     *
+     * @param nIso   1 = the reference algorithm; 8 = this build's isometry extension (rows then need isoN)
+     * @param isoN   int[N_r] receiving the winning isometry id per range block (all 0 for nIso = 1), may be null
+     */
+    public static native void encodeGrayMulti(int[] argb, int width, int height, int blockgroesse, int widthKernel,
+                                              int nIso, int nGpus, float[] out3N, int[] quant3N, int[] isoN);
+
+    /**
      * Replaces the search of encodeRGB, FractalCompression.java:181-215.
      *
      * @param out5N  float[N_r*5] receiving imageInfoRGB rows {i_local, a, bR, bG, bB} (FractalCompression.java:185,212)

@@ -78,8 +78,22 @@ FIC_API int fic_encode_gray_argb(const int32_t* argb, int w, int h, int B, int w
 FIC_API int fic_encode_gray_u8(const uint8_t* gray, int w, int h, int B, int wK, int n_iso, int device,
                                int32_t* idx_local, float* a, float* b, int32_t* iso, int32_t* qrows);
 
+/* The same call sharded over the first n_gpus HIP devices of the node, still ONE synchronous call on one host thread --
+ * what FractalCompression.encode (FractalCompression.java:54-59) is to its caller (RLEAppController.java:172-188).  The
+ * range loop it replaces (:125-159) carries no state between iterations: device g sweeps a contiguous, tile-aligned span
+ * of range blocks against its own replica of the pool (built from the replicated image), and the 24-byte codebook
+ * records are gathered to device 0 with one grouped RCCL send/recv over xGMI (librccl is loaded on first use; n_gpus = 1
+ * is exactly fic_encode_gray_argb on device 0 and needs no RCCL).  Results do not depend on n_gpus.
+ * Environment: FIC_GATHER=copy replaces the RCCL gather by peer-to-peer copies; FIC_FAKE_DEVICES=k (test knob) lets
+ * n_gpus exceed the visible devices up to k, logical devices sharing the real ones round-robin (gather by device copies:
+ * RCCL does not allow two ranks on one device). */
+FIC_API int fic_encode_gray_argb_multi(const int32_t* argb, int w, int h, int B, int wK, int n_iso, int n_gpus,
+                                       int32_t* idx_local, float* a, float* b, int32_t* iso, int32_t* qrows);
+FIC_API int fic_encode_gray_u8_multi(const uint8_t* gray, int w, int h, int B, int wK, int n_iso, int n_gpus,
+                                     int32_t* idx_local, float* a, float* b, int32_t* iso, int32_t* qrows);
+
 /* The one-shot entries (grey and RGB) keep the device working sets of the last few geometries (the GUI
- * re-encodes the same image on every slider move, RLEAppController.java:125-145); this frees them. */
+ * re-encodes the same image on every slider move, RLEAppController.java:125-145); this frees them, and the RCCL communicators of the multi-device entries. */
 FIC_API void fic_release_cache(void);
 
 /* writeData, grey branch (FractalCompression.java:230-246): big-endian int32 header
@@ -170,6 +184,8 @@ FIC_API int fic_ctx_decode_host(fic_ctx* ctx, uint8_t* gray_out, float* avg_erro
  *                     operands (centred pixels are exact bf16) at B = 4/8 and at B = 16 with 8 isometries, i8
  *                     operands at B = 16 with 1 isometry -- whichever is faster
  *                 4 = matrix-core sweep with i8 operands at every block size (the round's first kernels; kept)
+ *                 6 = the DEFAULT full-search sweep k_sweep_q (fic_q.hip): f16 matrix-core prune GEMM on a normalised domain
+ *                     operand + exact evaluation of the surviving pairs (B = 4/8/16, n_iso = 1 or 8)
  *                 (with "sweep" = 0 the environment variable FIC_SWEEP=3 selects the matrix-core sweep process-wide
  *                 for full-search launches of >= 5e7 (B = 4/8) / 5e8 (B = 16) (range, domain) pairs; smaller
  *                 launches and windowed search keep the VALU sweep, which is faster there)
@@ -179,12 +195,19 @@ FIC_API int fic_ctx_set_option(fic_ctx* ctx, const char* name, int value);
 /* Sum of sweep-kernel durations (ms) and launch count since the last reset ("time_sweep" = 1).
  * Synchronises the events.  reset != 0 clears the accumulators afterwards. */
 FIC_API int fic_ctx_sweep_time(fic_ctx* ctx, double* total_ms, int* launches, int reset);
+/* Counters of the default sweep k_sweep_q since the last reset (option "sweep_stats" = 1 first): out[0] tile epilogues
+ * (32 range copies x 32 domain blocks each), out[1] tiles that had flagged pairs, out[2] pairs evaluated exactly,
+ * out[3] waves.  Synchronises the context's stream. */
+FIC_API int fic_ctx_sweep_stats(fic_ctx* ctx, uint64_t* out4, int reset);
 /* Geometry actually in use: out[0..9] = Rw, Rh, N_r, Dw, Dh, N_d, NR, tiles, chunks, sweep kind. */
 FIC_API int fic_ctx_info(fic_ctx* ctx, int* out10);
 
 /* Test hook: out[i] = sqrt((double)(first + i)) computed on the device exactly as the pool
  * kernel does for Domainblock.variance (FractalCompression.java:677,680 Math.sqrt). */
 FIC_API int fic_debug_sqrt_f64(int device, uint32_t first, uint32_t count, double* out);
+/* Test hook: loads RCCL, creates one communicator per device 0..n-1 and (n >= 2) runs the codebook gather's grouped
+ * send/recv pattern on dummy records, checking what arrives on device 0. */
+FIC_API int fic_debug_rccl_selftest(int n);
 /* Test hook: copies the pool of the last encode to the host: pix u8 [planes][N_d][n],
  * sum u32 [planes][N_d], var u32 [planes][N_d], scaled u8 [planes][h/2][w/2]. NULLs allowed. */
 FIC_API int fic_ctx_debug_pool_host(fic_ctx* ctx, uint8_t* pix, uint32_t* sum, uint32_t* var, uint8_t* scaled);

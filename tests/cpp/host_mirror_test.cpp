@@ -2,6 +2,8 @@
 // (RLEAppController.java:172-188) drives the reference: set the two statics, encode(image, out), decode(in).
 //   host_mirror_test encode      <gray.raw u8>   w h B wK out.run collage.raw
 //   host_mirror_test encode_argb <argb.raw i32>  w h B wK out.run collage.raw     (colour -> encodeRGB)
+//   host_mirror_test encode_multi <gray.raw u8>  w h B wK n_iso n_gpus out.run     (fic_encode_gray_argb_multi: what the
+//                                                                                  JNI host calls on a multi-GPU node)
 //   host_mirror_test decode      <in.run> out_argb.raw                            (prints avgError)
 //   host_mirror_test synth       U|S w h seed out.raw                             (include/fic_synth.h; no GPU needed)
 //   host_mirror_test kernel      Dw Dh index wK                                   (prints generateKernel's dy dx; no GPU needed)
@@ -29,6 +31,33 @@ static int run(int argc, char** argv)
         fic_synth_image(argv[2][0], w, h, std::strtoull(argv[5], nullptr, 0), img.data());
         std::ofstream o(argv[6], std::ios::binary);
         o.write(reinterpret_cast<const char*>(img.data()), (std::streamsize)img.size());
+        return 0;
+    }
+    if (argc == 10 && !std::strcmp(argv[1], "encode_multi")) {
+        const int w = std::atoi(argv[3]), h = std::atoi(argv[4]), B = std::atoi(argv[5]), wK = std::atoi(argv[6]);
+        const int n_iso = std::atoi(argv[7]), n_gpus = std::atoi(argv[8]);
+        std::vector<unsigned char> g((size_t)w * h);
+        std::ifstream in(argv[2], std::ios::binary);
+        in.read(reinterpret_cast<char*>(g.data()), (std::streamsize)g.size());
+        if (!in) { std::fprintf(stderr, "short read\n"); return 2; }
+        std::vector<int32_t> argb(g.size());
+        for (size_t i = 0; i < g.size(); i++)
+            argb[i] = (int32_t)(0xff000000u | ((uint32_t)g[i] << 16) | ((uint32_t)g[i] << 8) | g[i]);
+        int Rw = 0, Rh = 0;
+        if (fic_geometry(w, h, B, &Rw, &Rh, nullptr, nullptr) < 0) throw std::runtime_error(fic_last_error());
+        const int nr = Rw * Rh;
+        std::vector<int32_t> idx(nr), iso(nr), q((size_t)nr * 3);
+        std::vector<float> a(nr), b(nr);
+        if (fic_encode_gray_argb_multi(argb.data(), w, h, B, wK, n_iso, n_gpus, idx.data(), a.data(), b.data(), iso.data(), q.data()) < 0)
+            throw std::runtime_error(fic_last_error());
+        std::vector<uint8_t> buf(20 + 12 * (size_t)nr);
+        const int64_t n = fic_write_run_gray(q.data(), nr, w, h, B, wK, buf.data(), (int64_t)buf.size());
+        if (n < 0) throw std::runtime_error(fic_last_error());
+        std::ofstream o(argv[9], std::ios::binary);
+        o.write(reinterpret_cast<const char*>(buf.data()), n);
+        o.write(reinterpret_cast<const char*>(iso.data()), (std::streamsize)(iso.size() * 4));     // + isometry ids, for the test
+        o.write(reinterpret_cast<const char*>(a.data()), (std::streamsize)(a.size() * 4));
+        o.write(reinterpret_cast<const char*>(b.data()), (std::streamsize)(b.size() * 4));
         return 0;
     }
     if (argc >= 4 && !std::strcmp(argv[1], "decode")) {

@@ -47,13 +47,17 @@ def test_d4_sweep_matches_oracle(oracle, name, chunks):
     assert same_f32(got["err"], ref["err"])
 
 
-def test_d4_is_the_default_where_it_exists_and_refused_elsewhere():
+def test_d4_is_the_valu_only_choice_where_it_exists_and_refused_elsewhere():
     g = IMAGES["U128"]
-    with fic_amd.Encoder(128, 128, 8, None, 8) as enc:
-        enc.set_gray(g)
+    with fic_amd.Encoder(256, 256, 8, None, 8) as enc:
+        enc.set_gray(IMAGES["lena256"])
+        enc.encode()
+        assert enc.info()["sweep_kind"] == 6          # library default: the matrix-core sweep
+        auto = {k: v.copy() for k, v in enc.results().items()}
+        enc.set_option("sweep", 5)
         enc.encode()
         assert enc.info()["sweep_kind"] == 5
-        auto = {k: v.copy() for k, v in enc.results().items()}
+        _same(auto, enc.results())
         enc.set_option("sweep", 2)
         enc.encode()
         assert enc.info()["sweep_kind"] == 2
@@ -62,7 +66,8 @@ def test_d4_is_the_default_where_it_exists_and_refused_elsewhere():
         with fic_amd.Encoder(128, 128, B, None, n_iso) as enc:
             enc.set_gray(g)
             enc.encode()
-            assert enc.info()["sweep_kind"] == 2
+            # below 2e6 (range, domain) pairs a launch stays on the VALU sweep, above it takes the matrix-core sweep
+            assert enc.info()["sweep_kind"] == (6 if enc.n_ranges * enc.n_domains >= 2000000 else 2)
             enc.set_option("sweep", 5)
             with pytest.raises(fic_amd.FicError):
                 enc.encode()

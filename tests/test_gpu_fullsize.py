@@ -115,13 +115,14 @@ def test_whole_codebook_at_full_size_valu_equals_matrix_core(size, B, n_iso, dis
     res = {}
     with fic_amd.Encoder(size, size, B, None, n_iso) as enc:
         enc.set_gray(g)
-        for sweep in (2, 3) + ((5,) if (B == 8 and n_iso == 8) else ()):     # 5: k_sweep_d4, the default there
+        for sweep in (2, 3, 6) + ((5,) if (B == 8 and n_iso == 8) else ()):     # 6: k_sweep_q, the default; 5: k_sweep_d4
             enc.set_option("sweep", sweep)
             enc.encode()
             res[sweep] = {k: v[0].copy() for k, v in enc.results().items()}
             assert enc.info()["sweep_kind"] == sweep
         wK = enc.wK
     _same(res[2], res[3])
+    _same(res[2], res[6])
     if 5 in res:
         _same(res[2], res[5])
     runs = [hashlib.sha256(fic_amd.write_run_gray(res[s]["qrows"], size, size, B, wK)).hexdigest() for s in (2, 3)]

@@ -121,15 +121,16 @@ def test_mfma1_equals_valu_sweep_at_scale_and_sharded(B, size):
     _same(cat, valu)
 
 
-def test_fic_sweep_environment_opt_in(tmp_path):
-    """FIC_SWEEP=3 selects the matrix-core sweep process-wide for launches with enough work (>= 5e8 range x domain
-    pairs), leaves small launches on the VALU sweep (faster there), and nothing else changes."""
+def test_fic_sweep_environment_override(tmp_path):
+    """The automatic choice (no option set): full search -> the matrix-core sweep k_sweep_q ("sweep" 6), except launches too
+    small to pay for fragment prep.  FIC_SWEEP=<n> overrides it process-wide: 5 = the VALU-only sweeps north_star describes
+    (k_sweep_d4 where built, else k_sweep_fast), 3 = the exact-covariance matrix-core sweeps.  Same codebooks every time."""
     import subprocess
     import sys
     code = (
         "import sys, numpy as np; sys.path.insert(0, %r); import fic_amd; from fic_amd import synth\n"
         "out = []\n"
-        "for size, planes, B, n_iso in [(256, 1, 8, 8), (1024, 1, 8, 8), (1024, 1, 8, 1), (1024, 8, 16, 8)]:\n"
+        "for size, planes, B, n_iso in [(64, 1, 8, 8), (256, 1, 8, 8), (1024, 1, 8, 1), (512, 2, 16, 8)]:\n"
         "    g = np.stack([synth.image_s(size, size, 3 + p) for p in range(planes)])\n"
         "    with fic_amd.Encoder(size, size, B, None, n_iso, planes) as e:\n"
         "        e.set_gray(g); e.encode(); r = e.results(); out.append((e.info()['sweep_kind'], r['qrows'].ravel(), r['iso'].ravel()))\n"
@@ -137,13 +138,15 @@ def test_fic_sweep_environment_opt_in(tmp_path):
         "np.save(sys.argv[2], np.concatenate([o[1] for o in out] + [o[2] for o in out]))\n"
     ) % os.path.dirname(os.path.dirname(GOLDEN))
     res = {}
-    for tag, env in (("valu", {}), ("mfma", {"FIC_SWEEP": "3"})):
+    for tag, env in (("auto", {}), ("valu", {"FIC_SWEEP": "5"}), ("mfma", {"FIC_SWEEP": "3"})):
         k, q = str(tmp_path / f"k_{tag}.npy"), str(tmp_path / f"q_{tag}.npy")
-        subprocess.check_call([sys.executable, "-c", code, k, q], env={**os.environ, **env})
+        e = {kk: v for kk, v in os.environ.items() if kk != "FIC_SWEEP"}
+        subprocess.check_call([sys.executable, "-c", code, k, q], env={**e, **env})
         res[tag] = (np.load(k), np.load(q))
-    assert res["valu"][0].tolist() == [5, 5, 2, 2]       # default VALU sweeps: k_sweep_d4 at B = 8 with 8 isometries, else k_sweep_fast
-    assert res["mfma"][0].tolist() == [5, 3, 3, 3]       # the single 256x256 image stays on the VALU sweep
-    assert (res["valu"][1] == res["mfma"][1]).all()
+    assert res["auto"][0].tolist() == [5, 6, 6, 6]       # 64x64: 64 ranges x 169 blocks stays on the VALU sweep
+    assert res["valu"][0].tolist() == [5, 5, 2, 2]       # k_sweep_d4 at B = 8 with 8 isometries, else k_sweep_fast
+    assert res["mfma"][0].tolist() == [3, 3, 3, 3]
+    assert (res["auto"][1] == res["valu"][1]).all() and (res["auto"][1] == res["mfma"][1]).all()
 
 
 # ---- n_iso = 8 at B = 4 and B = 16 (k_sweep_mfma<1>, <8>) ------------------------------------------------------

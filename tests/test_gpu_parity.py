@@ -467,6 +467,8 @@ def test_minimum_geometries(oracle, w, h, B, wK, n_iso):
     sweeps = [0, 1] + ([2] if wK == Dw == Dh else [])
     if wK == Dw == Dh and (n_iso == 1 or B == 8):
         sweeps.append(3)
+    if wK == Dw == Dh:
+        sweeps.append(6)
     for sweep in sweeps:
         got = fic_amd.encode_gray(g, B, wK, n_iso, sweep=sweep)
         _assert_same(oracle, got, ref)
@@ -504,7 +506,7 @@ def test_seeded_fuzz_geometries_windows_sweeps(oracle):
         ref = oracle.encode_gray(oracle.gray_to_argb(g), w, h, B, wK, n_iso)
         sweeps = [1]
         if wK == Dw == Dh:
-            sweeps += [2, 3, 4]                         # VALU, matrix-core (bf16 / i8 by block size), matrix-core i8
+            sweeps += [2, 3, 4, 6]                      # VALU, matrix-core (bf16 / i8 by block size), matrix-core i8, k_sweep_q
             if B == 8 and n_iso == 8:
                 sweeps.append(5)                        # VALU with algebraic isometries (k_sweep_d4)
         for sweep in sweeps:
@@ -555,7 +557,7 @@ def test_near_tie_images(oracle, B, n_iso, density):
     g = _near_tie_image(128, 128, 7 + B + n_iso, density)
     Dw = fic_amd.geometry(128, 128, B)[2]
     ref = _oracle_encode(oracle, g, B, Dw, n_iso)
-    sweeps = [2, 1] + ([3] if (n_iso == 1 or B == 8) else [])
+    sweeps = [2, 1, 6] + ([3] if (n_iso == 1 or B == 8) else [])
     for sweep in sweeps:
         for chunks in ((0, 3) if sweep >= 2 else (0,)):
             got = fic_amd.encode_gray(g, B, None, n_iso, sweep=sweep, chunks=chunks)

@@ -1,0 +1,141 @@
+"""k_sweep_q (fic_q.hip, "sweep" = 6, the library default for full search): the matrix cores compute an APPROXIMATE
+|cov|/sqrt(var) (normalised f16 domain operand) that only decides which pairs are evaluated exactly.  Same bar as every
+other sweep -- bit-identical codebooks against the oracle -- plus inputs that force its own rare branches (rule 26 of the
+CDNA guide: a rare data-dependent branch needs an input that takes it):
+  * low-contrast range blocks: the first domain tile of a chunk cannot seed theta out of order (L < 0.26 n) and is evaluated whole;
+  * letterboxed images: whole domain tiles flat before anything was evaluated (theta still "none");
+  * near-ties and exact duplicates: pairs within the error bound E_r of the running best must all be evaluated;
+  * every chunk count: each chunk start re-seeds theta; candidate 0 must always be evaluated (all-ties fallback winner)."""
+import os
+
+import numpy as np
+import pytest
+
+import fic_amd
+from fic_amd import synth
+from conftest import GOLDEN, same_f32
+
+pytestmark = pytest.mark.gpu
+
+
+def _letterbox(size, seed, bar):
+    g = synth.image_u(size, size, seed).copy()
+    g[:bar] = 16
+    g[-bar:] = 16
+    return g
+
+
+def _low_contrast(size, seed):
+    """+-1/+-2 texture on slow ramps: ||r - rM|| of a few units, so L < 0.26 n for every pair of most ranges."""
+    rng = np.random.default_rng(seed)
+    y, x = np.mgrid[0:size, 0:size]
+    return (100 + (x // 37) + (y // 53) + rng.integers(-2, 3, (size, size))).astype(np.uint8)
+
+
+def _duplicates(size, seed):
+    """A 16x16 tile repeated everywhere: every domain block occurs dozens of times (exact ties, lowest index must win)."""
+    rng = np.random.default_rng(seed)
+    return np.tile(rng.integers(0, 256, (16, 16)).astype(np.uint8), (size // 16, size // 16))
+
+
+def _one_noisy_block(size, seed):
+    g = np.full((size, size), 90, np.uint8)
+    g[size // 2:size // 2 + 16, size // 2:size // 2 + 16] = synth.image_u(16, 16, seed)
+    return g
+
+
+IMAGES = {
+    "lena64": np.load(os.path.join(GOLDEN, "lena64.npy")),
+    "lena256": np.load(os.path.join(GOLDEN, "lena_grey_256.npy")),
+    "U128": synth.image_u(128, 128, synth.SEEDS["cfg2"]),
+    "S128": synth.image_s(128, 128, synth.SEEDS["cfg2"]),
+    "S256": synth.image_s(256, 256, synth.SEEDS["cfg3"]),
+    "U200": synth.image_u(200, 200, 11),     # partial range group and partial domain tile
+    "flat64": np.full((64, 64), 77, np.uint8),
+    "letterbox": _letterbox(192, 5, 40),
+    "lowcontrast": _low_contrast(160, 6),
+    "duplicates": _duplicates(128, 7),
+    "onenoisy": _one_noisy_block(128, 8),
+    "ramp": ((np.arange(160)[None, :] * 3 + np.arange(160)[:, None] * 5) % 256).astype(np.uint8),
+}
+
+_CACHE = {}
+
+
+def _ref(oracle, name, B, n_iso):
+    key = (name, B, n_iso)
+    if key not in _CACHE:
+        g = IMAGES[name]
+        h, w = g.shape
+        Dw = fic_amd.geometry(w, h, B)[2]
+        _CACHE[key] = oracle.encode_gray(oracle.gray_to_argb(g), w, h, B, Dw, n_iso)
+    return _CACHE[key]
+
+
+def _check(oracle, got, ref):
+    want = ref["info"][:, 0].astype(np.int32)
+    bad = np.nonzero(got["idx_local"] != want)[0]
+    assert bad.size == 0, f"{bad.size} index mismatches, first at range {bad[0]}: got {got['idx_local'][bad[0]]} want {want[bad[0]]}"
+    assert (got["iso"] == ref["iso"]).all()
+    assert same_f32(got["a"], ref["info"][:, 1]) and same_f32(got["b"], ref["info"][:, 2])
+    assert (got["qrows"] == oracle.quantise_gray(ref["info"])).all()
+    assert same_f32(got["err"], ref["err"])
+
+
+CASES = [(n, B, k) for n in sorted(IMAGES) for B in (4, 8, 16) for k in (1, 8)
+         if not (B == 16 and n in ("lena64", "flat64", "U200")) and not (B == 4 and n in ("lena256", "S256", "letterbox"))]
+
+
+@pytest.mark.parametrize("name,B,n_iso", CASES)
+def test_q_sweep_matches_oracle(oracle, name, B, n_iso):
+    g = IMAGES[name]
+    ref = _ref(oracle, name, B, n_iso)
+    for chunks in (0, 1, 3):
+        got = fic_amd.encode_gray(g, B, None, n_iso, sweep=6, chunks=chunks)
+        _check(oracle, got, ref)
+
+
+@pytest.mark.parametrize("name,B,n_iso", [("lowcontrast", 8, 8), ("letterbox", 8, 1), ("duplicates", 8, 8), ("S128", 4, 8), ("U128", 16, 1)])
+def test_q_sweep_many_chunk_starts(oracle, name, B, n_iso):
+    """Up to one chunk per domain tile: every tile is a chunk's first tile (out-of-order seeding everywhere)."""
+    g = IMAGES[name]
+    ref = _ref(oracle, name, B, n_iso)
+    for chunks in (7, 50, 10000):
+        got = fic_amd.encode_gray(g, B, None, n_iso, sweep=6, chunks=chunks)
+        _check(oracle, got, ref)
+
+
+def test_q_is_the_default_batched_and_sharded(oracle):
+    imgs = [IMAGES["lena256"], IMAGES["S256"], synth.image_u(256, 256, 77)]
+    for n_iso in (1, 8):
+        with fic_amd.Encoder(256, 256, 8, None, n_iso, planes=3) as enc:
+            enc.set_gray(np.stack(imgs))
+            enc.encode()
+            assert enc.info()["sweep_kind"] == 6
+            whole = {k: v.copy() for k, v in enc.results().items()}
+            spans = fic_amd.shard_spans(enc.n_ranges, enc.ranges_per_tile, 3)
+            parts = []
+            for b, c in spans:                               # three logical shards, results gathered per span
+                enc.encode(b, c)
+                r = enc.results()
+                parts.append({k: v[:, b:b + c].copy() for k, v in r.items()})
+        for k in ("idx_local", "iso", "qrows"):
+            assert (np.concatenate([p[k] for p in parts], axis=1) == whole[k]).all()
+        for p, g in enumerate(imgs):
+            Dw = fic_amd.geometry(256, 256, 8)[2]
+            ref = oracle.encode_gray(oracle.gray_to_argb(g), 256, 256, 8, Dw, n_iso)
+            _check(oracle, {k: v[p] for k, v in whole.items()}, ref)
+
+
+def test_q_records_are_the_packed_results():
+    import torch
+    g = IMAGES["S256"]
+    with fic_amd.Encoder(256, 256, 8, None, 8) as enc:
+        enc.set_gray(g)
+        enc.encode()
+        r = enc.results()
+        rec = enc.records_device().cpu().numpy()
+    back = fic_amd.unpack_records(rec)
+    for k in ("idx_local", "iso", "qrows"):
+        assert (back[k] == r[k]).all()
+    assert same_f32(back["a"], r["a"]) and same_f32(back["b"], r["b"])

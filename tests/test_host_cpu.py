@@ -226,3 +226,20 @@ def oracle_iso_source(k, B, x, y):
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
     import fic_oracle
     return fic_oracle.lib().fo_iso_source(k, B, x, y)
+
+
+def test_jni_shim_parses_against_a_stub_jni_h():
+    """No JDK in the image: the JNI shim cannot be built, but gcc can parse and type-check it against a declaration-only
+    stand-in for jni.h (tests/jni_stub/jni.h: the JNI-spec signatures of the JNIEnv entries the shim uses) and the real
+    include/fic.h -- so every fic_* call in it matches the C ABI.  Also: the shim must never hold a JNI critical region."""
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = os.path.join(root, "fractal-image-compression_amd", "jni", "fic_jni.c")
+    r = subprocess.run(["gcc", "-fsyntax-only", "-std=c11", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(root, "tests", "jni_stub"),
+                        "-I" + os.path.join(root, "include"), src], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    code = open(src).read().split("*/", 1)[1]
+    assert "PrimitiveArrayCritical" not in code
+    java = open(os.path.join(root, "fractal-image-compression_amd", "java", "bvk_ss19", "FicNative.java")).read()
+    for name in ("deviceCount", "encodeGray", "encodeGrayMulti", "encodeRgb", "decode"):
+        assert f"native " in java and f" {name}(" in java and f"Java_bvk_1ss19_FicNative_{name}(" in code
