@@ -101,11 +101,11 @@ struct fic_ctx {
     void* mfma_sw = nullptr;
     int* mfma_rconst = nullptr;
     int mfma_bf16 = 0;               // operand type the fragment stores were built for
-    void* q_pool = nullptr;          // k_sweep_q ("sweep" = 6): A fragments, flat-tile flags, B fragments, error bounds, u8 copies
+    void* q_pool = nullptr;          // k_sweep_q ("sweep" = 6): A fragments, flat-tile flags, B fragments, error bounds, published theta
     void* q_flat = nullptr;
     void* q_rng = nullptr;
     void* q_E = nullptr;
-    void* q_u8 = nullptr;
+    void* q_thg = nullptr;
     unsigned long long* q_stats = nullptr;   // "sweep_stats" = 1: device counters of k_sweep_q (fic_ctx_sweep_stats)
     uint32_t* d4_rng = nullptr;      // k_sweep_d4: range / domain slots of the group-Fourier form (n_iso = 8, B = 8 / 16)
     uint32_t* d4_pool = nullptr;
@@ -136,7 +136,7 @@ int ctx_free_all(fic_ctx* c)
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
     c->ev.clear();
     if (c->own_stream) { (void)hipStreamDestroy(c->own_stream); c->own_stream = nullptr; }
-    void* ptrs[] = {c->gray_own, c->argb_stage, c->collage, c->decoded, c->mfma_poolB, c->mfma_rngA, c->mfma_sw, c->mfma_rconst, c->q_pool, c->q_flat, c->q_rng, c->q_E, c->q_u8, c->q_stats, c->d4_rng, c->d4_pool, c->b.scaled, c->b.pool_pix, c->b.pool_st, c->b.pool_var,
+    void* ptrs[] = {c->gray_own, c->argb_stage, c->collage, c->decoded, c->mfma_poolB, c->mfma_rngA, c->mfma_sw, c->mfma_rconst, c->q_pool, c->q_flat, c->q_rng, c->q_E, c->q_thg, c->q_stats, c->d4_rng, c->d4_pool, c->b.scaled, c->b.pool_pix, c->b.pool_st, c->b.pool_var,
                     c->b.pool_s64, c->b.rng_pix, c->b.rng_st, c->b.key, c->o.idx_local, c->o.idx_global, c->o.iso,
                     c->o.a, c->o.b, c->o.err, c->o.qrows, c->o.records};
     for (void* p : ptrs)
@@ -396,7 +396,8 @@ int matrix_core_sweep(fic_ctx* c, int kind, int tile0, int tile1, hipStream_t s,
 
 // Default full-search sweep (fic_q.hip): shapes of its stores, fused prep (pool build + range prep + fragments), launch.
 struct QShape {
-    int ndtiles, ndtiles_alloc;      // domain tiles (x32 blocks), + 2 spare for the prefetch
+    int ndtiles, ndtiles_alloc;      // domain tiles (x32 blocks), + zero tiles for the unrolled loop's overrun and prefetch
+    int unroll;                      // unroll factor of the sweep loop
     int CT;                          // column tiles (x32 range copies) per workgroup
     int nct_alloc;                   // column tiles allocated (padded for the last workgroup)
 };
@@ -404,7 +405,8 @@ QShape q_shape(const FicGeom& g)
 {
     QShape q;
     q.ndtiles = (g.Nd + 31) / 32;
-    q.ndtiles_alloc = q.ndtiles + 2;
+    q.unroll = fic_q_unroll(g.B, g.n_iso);
+    q.ndtiles_alloc = q.ndtiles + 2 * q.unroll;
     q.CT = fic_q_ct(g.B);
     const int nct = g.Nr_pad * fic_q_cols_per_range(g.B, g.n_iso) / 32;
     q.nct_alloc = (nct + q.CT - 1) / q.CT * q.CT + q.CT;
@@ -422,10 +424,10 @@ int q_prep(fic_ctx* c, int tile0, int tile1, hipStream_t s)
         HIP_TRY(hipMemsetAsync(c->q_rng, 0, P * q.nct_alloc * NK * 64 * 16, s));
     }
     if (!c->q_E) HIP_TRY(hipMalloc(&c->q_E, P * g.Nr_pad * sizeof(float)));
-    if (!c->q_u8) HIP_TRY(hipMalloc(&c->q_u8, P * g.Nr_pad * g.n_iso * g.n));
+    if (!c->q_thg) HIP_TRY(hipMalloc(&c->q_thg, P * g.Nr_pad * sizeof(uint32_t)));
     const int tsz = 64 * g.NR;
     const int grp0 = tile0 * tsz / 64, grp1 = tile1 * tsz / 64;      // 64-range groups covering the span
-    if (fic_launch_q_prep(c->b, c->q_pool, c->q_flat, c->q_rng, c->q_E, c->q_u8, g, q.ndtiles_alloc, q.nct_alloc, grp0, grp1 - grp0, s))
+    if (fic_launch_q_prep(c->b, c->q_pool, c->q_flat, c->q_rng, c->q_E, c->q_thg, g, q.ndtiles_alloc, q.nct_alloc, grp0, grp1 - grp0, s))
         return fail(FIC_E_HIP, "k_pool_q / k_range_q launch failed");
     return FIC_OK;
 }
@@ -447,9 +449,10 @@ int q_sweep(fic_ctx* c, int tile0, int tile1, hipStream_t s, int* nchunks_out)
         nchunks = (int)(want < cap ? want : cap);
     }
     if (nchunks > q.ndtiles) nchunks = q.ndtiles;
-    const int tiles_per_chunk = (q.ndtiles + nchunks - 1) / nchunks;
+    int tiles_per_chunk = (q.ndtiles + nchunks - 1) / nchunks;
+    tiles_per_chunk = (tiles_per_chunk + q.unroll - 1) / q.unroll * q.unroll;     // whole iterations of the unrolled sweep loop
     nchunks = (q.ndtiles + tiles_per_chunk - 1) / tiles_per_chunk;
-    if (fic_launch_sweep_q(c->b, c->q_pool, c->q_flat, c->q_rng, c->q_E, c->q_u8, g, ct_begin, ct_end, q.ndtiles, q.ndtiles_alloc,
+    if (fic_launch_sweep_q(c->b, c->q_pool, c->q_flat, c->q_rng, c->q_E, c->q_thg, g, ct_begin, ct_end, q.ndtiles, q.ndtiles_alloc,
                            q.nct_alloc, tiles_per_chunk, nchunks, s, c->q_stats))
         return fail(FIC_E_HIP, "k_sweep_q launch failed");
     *nchunks_out = nchunks;

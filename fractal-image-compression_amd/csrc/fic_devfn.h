@@ -71,6 +71,64 @@ __device__ __forceinline__ int iso_source(int k, int B, int x, int y)
 }
 __device__ __forceinline__ int iso_inverse(int k) { return k == 1 ? 3 : (k == 3 ? 1 : k); }
 
+// The same map in affine form: iso_source(k, B, x, y) = sx + sy * B with
+//   sx = ax*x + bx*y + cx,  sy = ay*x + by*y + cy   (m = B - 1),
+// so a copy can be gathered with one multiply-add per pixel instead of a switch (and straight from an image with row
+// pitch W: offset = (cy*W + cx) + x*(ay*W + ax) + y*(by*W + bx)).
+__device__ __forceinline__ void iso_affine(int k, int m, int& ax, int& bx, int& cx, int& ay, int& by, int& cy)
+{
+    ax = bx = cx = ay = by = cy = 0;
+    switch (k) {
+    default:
+    case 0: ax = 1;          by = 1;          break;
+    case 1: bx = 1;          ay = -1; cy = m; break;
+    case 2: ax = -1; cx = m; by = -1; cy = m; break;
+    case 3: bx = -1; cx = m; ay = 1;          break;
+    case 4: ax = -1; cx = m; by = 1;          break;
+    case 5: ax = 1;          by = -1; cy = m; break;
+    case 6: bx = 1;          ay = 1;          break;
+    case 7: bx = -1; cx = m; ay = -1; cy = m; break;
+    }
+}
+
+// Exact sums of products of an isometry copy of a range block with a domain block, the range pixels gathered straight
+// from the image (no stored copies):
+//   s  = sum_pos copy_k[pos] * d[pos],     copy_k[pos] = r[iso_source(iso_inverse(k), pos)]      
+//   s2 = sum_pos copy_k[n-1-pos] * d[pos]  -- the copy of k's point-reflected partner isometry (0/2, 1/3, 4/5, 6/7) -- if PAIR
+// blk = top-left pixel of the range block in an image of row pitch W; dom = the domain block's n bytes as dwords.
+template <int B, bool PAIR>
+__device__ __forceinline__ void iso_dot(const uint8_t* __restrict__ blk, int W, int k, const uint32_t* __restrict__ dom,
+                                        uint32_t& s, uint32_t& s2)
+{
+    constexpr int n = B * B, CH = n < 64 ? n : 64, ROWS = CH / B;
+    int ax, bx, cx, ay, by, cy;
+    iso_affine(iso_inverse(k), B - 1, ax, bx, cx, ay, by, cy);
+    const int ox = ay * W + ax, oy = by * W + bx, o0 = cy * W + cx;
+    s = 0;
+    s2 = 0;
+    for (int c = 0; c < n / CH; c++) {                     // 64 positions at a time: one pass at B = 4 / 8, four at B = 16
+        const int obase = o0 + c * ROWS * oy;
+        uint32_t rw[CH / 4];
+#pragma unroll
+        for (int q = 0; q < CH / 4; q++) {
+            uint32_t w = 0;
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                const int pl = 4 * q + t;
+                w |= (uint32_t)blk[obase + (pl % B) * ox + (pl / B) * oy] << (8 * t);
+            }
+            rw[q] = w;
+        }
+#pragma unroll
+        for (int q = 0; q < CH / 4; q++) {
+            const int qg = c * (CH / 4) + q;
+            s = __builtin_amdgcn_udot4(rw[q], dom[qg], s, false);
+            // partner: sum_pos copy[n-1-pos] d[pos] = sum_q copy[q] d[n-1-q] -> the mirrored dword, bytes reversed
+            if constexpr (PAIR) s2 = __builtin_amdgcn_udot4(rw[q], __builtin_bswap32(dom[n / 4 - 1 - qg]), s2, false);
+        }
+    }
+}
+
 // getDomainBlockIndex FC:516-545
 __device__ __forceinline__ int domain_block_index(int xr, int yr, int Rw, int Rh, int Dw)
 {

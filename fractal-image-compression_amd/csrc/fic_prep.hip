@@ -214,14 +214,12 @@ __global__ __launch_bounds__(256) void k_finalize(const uint32_t* __restrict__ p
     FicRngStat rs = rng_st[(size_t)plane * g.Nr_pad + j];
     uint32_t acc = 0;
     if (gray) {
-        // the winner's copy straight from the image: copy_k[pos] = r[iso_source(iso_inverse(k), pos)]  (k_range_copies)
+        // the winner's copy straight from the image: copy_k[pos] = r[iso_source(iso_inverse(k), pos)]  (affine gather, fic_devfn.h)
         const uint8_t* blk = gray + (size_t)plane * g.W * g.H + (size_t)((j / g.Rw) * g.B) * g.W + (j % g.Rw) * g.B;
-        const uint8_t* pb = (const uint8_t*)pp;
-        const int ki = iso_inverse(k);
-        for (int pos = 0; pos < g.n; pos++) {
-            const int src = iso_source(ki, g.B, pos % g.B, pos / g.B);
-            acc += (uint32_t)blk[(size_t)(src / g.B) * g.W + src % g.B] * (uint32_t)pb[pos];
-        }
+        uint32_t s2;
+        if (g.B == 4) iso_dot<4, false>(blk, g.W, k, pp, acc, s2);
+        else if (g.B == 8) iso_dot<8, false>(blk, g.W, k, pp, acc, s2);
+        else iso_dot<16, false>(blk, g.W, k, pp, acc, s2);
     } else {
         for (int dw = 0; dw < g.DW; dw++) acc = __builtin_amdgcn_udot4(rp[rng_word_index(g, j, k, dw)], pp[dw], acc, false);
     }

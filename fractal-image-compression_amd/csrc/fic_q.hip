@@ -62,6 +62,8 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 #define FIC_Q_QFLUSH 256                   // evaluate the queue before a tile's pushes once it holds this many
 
 __host__ __device__ constexpr int fic_q_ctw(int NK) { return NK <= 4 ? 4 : 2; }   // column tiles (x32 range copies) per wave
+// prefetch distance of the domain fragments in tiles (= VGPR buffers - 1 = the sweep loop's unroll factor - 1)
+__host__ __device__ constexpr int fic_q_pf(int NK, int MODE) { return (NK == 4 && MODE != 2) ? 2 : 1; }
 
 // two floats -> packed f16 pair (round to nearest even), element 0 in the low half
 __device__ __forceinline__ int f16_pair(float lo, float hi)
@@ -174,24 +176,25 @@ __global__ __launch_bounds__(256) void k_pool_q(const uint8_t* __restrict__ scal
 // ---------------------------------------------------------------------------------------------
 // k_range_q : one workgroup per 64 range blocks.  getRangeblock FC:588-602 (R-channel bytes, row-major), getMittelwert
 // FC:67-73 (rM = sum / n, int), rem = sum - n*rM (= varianzRange after the loop at FC:665-672), the error bound E_r, the
-// search key reset, the u8 isometry copies for the exact path, and the B fragments for k_sweep_q.
+// reset of the search key and of the published theta, and the B fragments for k_sweep_q.
 //   copy_k[pos] = r[iso_source(iso_inverse(k), pos)]  so that  dot(copy_k, d) == dot(r, iso_k(d))   
 //   column rr of the sweep: mode 0 (1 isometry): range rr; mode 1 (8 isometries, direct): range rr >> 3, copy rr & 7;
 //   mode 2 (8 isometries, folded): range rr >> 2, isometry pair rr & 3 = {0,2}, {1,3}, {4,5}, {6,7}.
 //   rngQ[plane][ctile][m][lane] = 8 f16 of column 32*ctile + (lane&31), h = lane>>5: centred pixels [16m + 8h, +8) of the
 //   copy; folded: steps m < NK/2 the even part c + c' of positions [16m + 8h, +8), steps m >= NK/2 the odd part c - c'.
-//   rng_u8[plane][j][k][n] bytes.
+// Statistics: 4 threads per block (byte sums by v_sad_u8, squares by v_dot4), combined inside the quad.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_range_q(const uint8_t* __restrict__ gray, FicRngStat* __restrict__ rng_st,
                                                  float* __restrict__ rngE, unsigned long long* __restrict__ key,
-                                                 uint8_t* __restrict__ rng_u8, v4i* __restrict__ rngQ, FicGeom g,
+                                                 uint32_t* __restrict__ theta_g, v4i* __restrict__ rngQ, FicGeom g,
                                                  int nct_alloc, int grp0, int mode)
 {
     __shared__ __attribute__((aligned(16))) uint8_t blk[64 * (256 + 4)];
     __shared__ int s_rM[64];
     const int plane = blockIdx.y;
     const int grp = grp0 + blockIdx.x;
-    const int B = g.B, n = g.n, DW = g.DW, NK = n / 16, n_iso = g.n_iso;
+    const int B = g.B, n = g.n, DW = g.DW, NK = n / 16;
+    const int lgB = B == 4 ? 2 : (B == 8 ? 3 : 4);
     const int stride = n + 4;
     const int j0 = grp * 64;
     const uint8_t* img = gray + (size_t)plane * g.W * g.H;
@@ -201,74 +204,73 @@ __global__ __launch_bounds__(256) void k_range_q(const uint8_t* __restrict__ gra
         uint32_t v = 0;
         if (j < g.Nr) {
             const int pos = wd * 4;
-            const uint8_t* p = img + (size_t)((j / g.Rw) * B + pos / B) * g.W + (j % g.Rw) * B + pos % B;
+            const uint8_t* p = img + (size_t)((j / g.Rw) * B + (pos >> lgB)) * g.W + (j % g.Rw) * B + (pos & (B - 1));
             v = *(const uint32_t*)p;                           // B, W multiples of 4: aligned
         }
         *(uint32_t*)&blk[l * stride + wd * 4] = v;
     }
     __syncthreads();
-    if (threadIdx.x < 64) {
-        const int j = j0 + threadIdx.x;
-        const uint8_t* b = blk + threadIdx.x * stride;
-        int S = 0;
-        for (int i = 0; i < n; i++) S += b[i];
-        const int rM = S >> g.lgn;
-        int ss = 0;
-        for (int i = 0; i < n; i++) { const int a = (int)b[i] - rM; ss += a * a; }
-        s_rM[threadIdx.x] = rM;
-        if (j < g.Nr_pad) {
-            const size_t o = (size_t)plane * g.Nr_pad + j;
-            FicRngStat st;
-            st.rM = j < g.Nr ? rM : 0;
-            st.rem = j < g.Nr ? S - (rM << g.lgn) : 0;
-            rng_st[o] = st;
-            rngE[o] = __fadd_rn(__fmul_rn(__fsqrt_rn((float)ss), FIC_Q_ECOEF), FIC_Q_EABS);
-            key[o] = FIC_KEY_NONE;
+    {
+        const int l = threadIdx.x >> 2, part = threadIdx.x & 3;   // 4 threads per block, DW/4 words each
+        const uint32_t* w = (const uint32_t*)(blk + l * stride) + part * (DW / 4);
+        uint32_t S = 0, Q = 0;
+        for (int i = 0; i < DW / 4; i++) {
+            S = __builtin_amdgcn_sad_u8(w[i], 0u, S);
+            Q = __builtin_amdgcn_udot4(w[i], w[i], Q, false);
+        }
+        S += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)S, 0xB1, 0xF, 0xF, true);   // quad: lanes 1,0,3,2
+        Q += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)Q, 0xB1, 0xF, 0xF, true);
+        S += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)S, 0x4E, 0xF, 0xF, true);   // quad: lanes 2,3,0,1
+        Q += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)Q, 0x4E, 0xF, 0xF, true);
+        const int j = j0 + l;
+        const int rM = (int)(S >> g.lgn);
+        if (part == 0) {
+            s_rM[l] = rM;
+            if (j < g.Nr_pad) {
+                const int ss = (int)Q - 2 * rM * (int)S + n * rM * rM;                    // sum (r - rM)^2, exact integer
+                const size_t o = (size_t)plane * g.Nr_pad + j;
+                FicRngStat st;
+                st.rM = j < g.Nr ? rM : 0;
+                st.rem = j < g.Nr ? (int)S - (rM << g.lgn) : 0;
+                rng_st[o] = st;
+                rngE[o] = __fadd_rn(__fmul_rn(__fsqrt_rn((float)ss), FIC_Q_ECOEF), FIC_Q_EABS);
+                key[o] = FIC_KEY_NONE;
+                theta_g[o] = 0u;
+            }
         }
     }
     __syncthreads();
-    // u8 isometry copies: thread = (range l, copy k, 4 pixels)
-    for (int o = threadIdx.x; o < 64 * n_iso * DW; o += 256) {
-        const int dw = o % DW, k = (o / DW) % n_iso, l = o / (DW * n_iso);
-        const int j = j0 + l;
-        if (j >= g.Nr) continue;
-        const int ki = iso_inverse(k);
-        const uint8_t* b = blk + l * stride;
-        uint32_t w = 0;
-#pragma unroll
-        for (int t = 0; t < 4; t++) {
-            const int pos = dw * 4 + t;
-            w |= (uint32_t)b[iso_source(ki, B, pos % B, pos / B)] << (8 * t);
-        }
-        ((uint32_t*)rng_u8)[(((size_t)plane * g.Nr_pad + j) * n_iso + k) * DW + dw] = w;
-    }
-    // fragments: thread = (column tile, m, lane)
+    // fragments: thread = (column tile, m, lane); the copy is gathered through the affine form of iso_source
     const int cpr = mode == 0 ? 1 : (mode == 1 ? 8 : 4);       // columns per range block
+    const int lgc = mode == 0 ? 0 : (mode == 1 ? 3 : 2);
     const int cols = 64 * cpr;                                 // columns of this workgroup
     const int ct0 = (j0 * cpr) / 32;
     for (int t = threadIdx.x; t < (cols / 32) * NK * 64; t += 256) {
         const int lane = t & 63, m = (t >> 6) % NK, ctl = (t >> 6) / NK;
         const int col = ctl * 32 + (lane & 31), h = lane >> 5;
-        const int l = col / cpr, c = col % cpr;
+        const int l = col >> lgc, c = col & (cpr - 1);
         const int k = mode == 2 ? (c == 0 ? 0 : (c == 1 ? 1 : (c == 2 ? 4 : 6))) : c;   // folded: the pair's first isometry
-        const int ki = iso_inverse(k);
+        int ax, bx, cx, ay, by, cy;
+        iso_affine(iso_inverse(k), B - 1, ax, bx, cx, ay, by, cy);
+        const int s0 = cx + cy * B, sx = ax + ay * B, sy = bx + by * B;                 // source index = s0 + sx*x + sy*y
         const uint8_t* b = blk + l * stride;
         const int rM = s_rM[l];
         const bool real = j0 + l < g.Nr;
         int a[8];
         if (mode != 2) {
+            const int p0 = 16 * m + 8 * h;
 #pragma unroll
             for (int u = 0; u < 8; u++) {
-                const int p0 = 16 * m + 8 * h + u;
-                a[u] = (int)b[iso_source(ki, B, p0 % B, p0 / B)] - rM;
+                const int p = p0 + u;
+                a[u] = (int)b[s0 + sx * (p & (B - 1)) + sy * (p >> lgB)] - rM;
             }
         } else {
             const bool odd = m >= NK / 2;
             const int q0 = 16 * (odd ? m - NK / 2 : m) + 8 * h;
 #pragma unroll
             for (int u = 0; u < 8; u++) {
-                const int p0 = q0 + u, p1 = n - 1 - p0;
-                const int c0 = b[iso_source(ki, B, p0 % B, p0 / B)], c1 = b[iso_source(ki, B, p1 % B, p1 / B)];
+                const int p = q0 + u, pr = n - 1 - p;
+                const int c0 = b[s0 + sx * (p & (B - 1)) + sy * (p >> lgB)], c1 = b[s0 + sx * (pr & (B - 1)) + sy * (pr >> lgB)];
                 a[u] = odd ? c0 - c1 : c0 + c1 - 2 * rM;
             }
         }
@@ -298,13 +300,14 @@ struct QArgs {
     const FicDomStat* pool_st;
     const double* pool_s64;
     const v4i* rngQ;                 // [plane][nct_alloc][NK][64]
-    const uint8_t* rng_u8;           // [plane][Nr_pad][n_iso][n]
+    const uint8_t* gray;             // [plane][H][W] the input image: range pixels of the exact path are gathered from it
     const FicRngStat* rng_st;
     const float* rngE;
     unsigned long long* key;
+    uint32_t* theta_g;               // [plane][Nr_pad] best published level per range (order-preserving integer image; 0 = none)
     unsigned long long* stats;       // optional [4]: tile epilogues, tiles with flagged pairs, queued entries, waves
-    int Nd, Nd_pad, Nr, Nr_pad, n, lgn;
-    int ndtiles, ndtiles_alloc, nct_alloc;
+    int Nd, Nd_pad, Nr, Nr_pad, n, lgn, W, H, Rw;
+    int ndtiles, ndtiles_loop, ndtiles_alloc, nct_alloc;   // ndtiles_loop: ndtiles rounded up to the loop's unroll factor
     int ct_begin, ct_end;            // column tiles (x32 columns) of this shard
     int nctg;                        // column-tile groups (workgroups) in this launch
     int tiles_per_chunk, nchunks, planes;
@@ -349,40 +352,27 @@ template <int NK, int MODE>
 __device__ __forceinline__ void q_flush(const QArgs& A, const uint32_t* myq, int qn, int plane, int ctw0, int lane)
 {
     constexpr int NISO = QMode<MODE>::NISO, CSHIFT = QMode<MODE>::CSHIFT;
+    constexpr int B = NK == 1 ? 4 : (NK == 4 ? 8 : 16);
     const FicRngStat* rst = A.rng_st + (size_t)plane * A.Nr_pad;
     const double* p64 = A.pool_s64 + (size_t)plane * A.Nd_pad;
     const FicDomStat* pst = A.pool_st + (size_t)plane * A.Nd_pad;
     unsigned long long* keyp = A.key + (size_t)plane * A.Nr_pad;
+    const uint8_t* img = A.gray + (size_t)plane * A.W * A.H;
     for (int base = 0; base < qn; base += 64) {
         const int i = base + lane;
         if (i < qn) {
             const uint32_t ent = myq[i];
             const uint32_t d = ent & 0x00FFFFFFu;
+            if (d >= (uint32_t)A.Nd) continue;                 // a zero row behind the pool, flagged while theta was "none"
             const int col = ctw0 * 32 + (int)(ent >> 24);
             const int j = col >> CSHIFT, k = q_col_iso<MODE>(col & ((1 << CSHIFT) - 1));
             const int k2 = k == 0 ? 2 : (k == 1 ? 3 : k + 1);                       // MODE 2: the pair's second isometry
-            const uint4* dp = (const uint4*)(A.pool_pix + ((size_t)plane * A.Nd_pad + d) * A.n);
-            const uint4* rp = (const uint4*)(A.rng_u8 + (((size_t)plane * A.Nr_pad + j) * NISO + k) * A.n);
-            const uint4* rp2 = (const uint4*)(A.rng_u8 + (((size_t)plane * A.Nr_pad + j) * NISO + k2) * A.n);
+            const uint8_t* blk = img + (size_t)((j / A.Rw) * B) * A.W + (j % A.Rw) * B;
             const FicRngStat rs = rst[j];
             const int Sd = (int)pst[d].sum;
             const double s64 = p64[d];
-            uint32_t s = 0, s2 = 0;
-#pragma unroll
-            for (int v = 0; v < NK; v++) {
-                const uint4 x = dp[v], y = rp[v];
-                s = __builtin_amdgcn_udot4(x.x, y.x, s, false);
-                s = __builtin_amdgcn_udot4(x.y, y.y, s, false);
-                s = __builtin_amdgcn_udot4(x.z, y.z, s, false);
-                s = __builtin_amdgcn_udot4(x.w, y.w, s, false);
-                if constexpr (MODE == 2) {
-                    const uint4 z = rp2[v];
-                    s2 = __builtin_amdgcn_udot4(x.x, z.x, s2, false);
-                    s2 = __builtin_amdgcn_udot4(x.y, z.y, s2, false);
-                    s2 = __builtin_amdgcn_udot4(x.z, z.z, s2, false);
-                    s2 = __builtin_amdgcn_udot4(x.w, z.w, s2, false);
-                }
-            }
+            uint32_t s, s2;
+            iso_dot<B, MODE == 2>(blk, A.W, k, (const uint32_t*)(A.pool_pix + ((size_t)plane * A.Nd_pad + d) * A.n), s, s2);
             const int base_c = rs.rM * Sd + (Sd >> A.lgn) * rs.rem;
             const float err = exact_error((int)s - base_c, rs.rem, s64);
             unsigned long long best = ((unsigned long long)f32_orderable(err) << 32) | (d * (uint32_t)NISO + (uint32_t)k);
@@ -396,6 +386,22 @@ __device__ __forceinline__ void q_flush(const QArgs& A, const uint32_t* myq, int
     }
 }
 
+// maximum over the lanes that share a range block: the two lane halves (rows 0-31 / 32-63 of the same column) and the
+// range's 2^CSHIFT adjacent columns.  Every lane of the wave must be active.
+template <int MODE>
+__device__ __forceinline__ float q_share_max(float v)
+{
+    if constexpr (QMode<MODE>::CSHIFT >= 2) {
+        v = fmaxf(v, __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), 0xB1, 0xF, 0xF, true)));   // quad_perm [1,0,3,2]
+        v = fmaxf(v, __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), 0x4E, 0xF, 0xF, true)));   // quad_perm [2,3,0,1]
+    }
+    if constexpr (QMode<MODE>::CSHIFT == 3)
+        v = fmaxf(v, __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), 0x141, 0xF, 0xF, true)));  // row_half_mirror
+    const uint32_t u = __float_as_uint(v);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);      // {lanes 0-31 twice, lanes 32-63 twice}
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+
 template <int NK, int MODE>
 __global__ __launch_bounds__(256) void k_sweep_q(QArgs A)
 {
@@ -403,8 +409,7 @@ __global__ __launch_bounds__(256) void k_sweep_q(QArgs A)
     constexpr int CSHIFT = QMode<MODE>::CSHIFT;
     constexpr bool FOLD = MODE == 2;
     constexpr int NKA = FOLD ? NK / 2 : NK;                  // MFMA steps per accumulator
-    __shared__ uint32_t sTau[4][CTW * 32];             // per wave, per range slot: theta as an order-preserving integer
-    __shared__ uint32_t sMax[4][CTW * 32];             // per wave, per range slot: largest test value of the chunk's first tile
+    constexpr int PF = fic_q_pf(NK, MODE);                   // prefetch distance in domain tiles = buffers - 1
     __shared__ uint32_t sQ[4][FIC_Q_QCAP];             // per wave: domain block | column-in-wave << 24
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -413,17 +418,16 @@ __global__ __launch_bounds__(256) void k_sweep_q(QArgs A)
     const int plane = combo_ / A.nchunks;
     const int chunk = combo_ % A.nchunks;
     const int ctw0 = A.ct_begin + gx_ * CT + wave * CTW;     // first column tile of this wave
-    const int dt0 = chunk * A.tiles_per_chunk;
-    int dt1 = dt0 + A.tiles_per_chunk;
-    if (dt1 > A.ndtiles) dt1 = A.ndtiles;
-    if (dt0 >= dt1 || ctw0 >= A.ct_end) return;              // (no barrier in this kernel: waves are independent)
+    const int dt0 = chunk * A.tiles_per_chunk;               // tiles_per_chunk is a multiple of the loop's unroll factor;
+    int dt1 = dt0 + A.tiles_per_chunk;                       // the last chunk runs into the store's zero tiles (flagged flat)
+    if (dt1 > A.ndtiles_loop) dt1 = A.ndtiles_loop;
+    if (dt0 >= A.ndtiles || ctw0 >= A.ct_end) return;        // (no barrier in this kernel: waves are independent)
     int nci = A.ct_end - ctw0;                               // column tiles this wave really owns (wave-uniform)
     if (nci > CTW) nci = CTW;
 
     const int jcol = lane & 31, half = lane >> 5;
     const FicRngStat* rst = A.rng_st + (size_t)plane * A.Nr_pad;
-    uint32_t* const myTau = sTau[wave];
-    uint32_t* const myMax = sMax[wave];
+    uint32_t* const thg = A.theta_g + (size_t)plane * A.Nr_pad;
     uint32_t* const myq = sQ[wave];
 
     v4i rb[CTW][NK];
@@ -448,9 +452,6 @@ __global__ __launch_bounds__(256) void k_sweep_q(QArgs A)
         tau[ci] = (ok && rem != 0) ? FIC_Q_TAU_NONE : FIC_Q_TAU_ALL;
         okbits |= ok ? 1u << ci : 0u;
         raise |= (ok && rem != 0) ? 1u << ci : 0u;
-        const int slot = (ci * 32 + jcol) >> CSHIFT;
-        myTau[slot] = f32_orderable(tau[ci]);                // (lanes sharing a slot write the same value)
-        myMax[slot] = 0u;
     }
 
     const v4i* pa = A.poolQ + (size_t)plane * A.ndtiles_alloc * NK * 64 + lane;
@@ -458,6 +459,7 @@ __global__ __launch_bounds__(256) void k_sweep_q(QArgs A)
     // the prefetched fragment loads as well: s_waitcnt vmcnt(0))
     const uint32_t AS4* pflat = (const uint32_t AS4*)(uintptr_t)(A.dflat + (size_t)plane * A.ndtiles_alloc);
     const v16f zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const float lmin = 0.26f * (float)A.n;                   // L of a pair that prunes regardless of index order (header)
     int qn = 0;                                              // queued entries (wave-uniform)
     unsigned st_slow = 0, st_pairs = 0;                      // instrumentation (wave-uniform; reported when A.stats is set)
 
@@ -469,53 +471,52 @@ __global__ __launch_bounds__(256) void k_sweep_q(QArgs A)
     auto val = [&](const v16f& acc, const v16f& acc2, int e) __attribute__((always_inline)) {
         return FOLD ? fabsf(acc[e]) + fabsf(acc2[e]) : fabsf(acc[e]);
     };
-    // a tile with flagged entries: queue them, raise theta.  FIRST: the chunk's first tile (theta was just seeded).
-    auto flagged_tile = [&](const v16f& acc, const v16f& acc2, float mx, int ci, int dt, bool first) __attribute__((always_inline)) {
+    // A tile with flagged entries (or a chunk's first tile): queue the entries, raise theta.
+    //   theta moves three ways: (1) FIRST: seeded from the tile's largest test value per range -- out of index order, hence
+    //   only when that pair's L >= lmin (header); (2) from the flagged entries of this tile (they have lower indices than
+    //   everything still to come in this chunk); (3) from theta_g, the best level any wave has published for the range --
+    //   other chunks, any index order, hence published only for pairs with L >= lmin.
+    auto slow_tile = [&](const v16f& acc, const v16f& acc2, float mx, int ci, int dt, bool first) __attribute__((always_inline)) {
         // only zeros flagged (theta still "none"): an all-flat tile seen before anything was evaluated needs nothing
         if (!first && __builtin_amdgcn_ballot_w64(mx > 0.0f) == 0 && pflat[dt] != 0u) return;
         if (qn > FIC_Q_QFLUSH) flush();
         st_slow++;
         const bool ok = (okbits >> ci) & 1u;
+        const bool mayraise = (raise >> ci) & 1u;
         const int colw = ci * 32 + jcol;                     // column in wave
-        const int slot = colw >> CSHIFT;
+        const int jg = ((ctw0 + ci) * 32 + jcol) >> CSHIFT;  // the column's range block (valid when ok)
+        // (3), consumed below so that the load overlaps the element loop; with one chunk no other wave sees this range
+        const uint32_t g = (mayraise && A.nchunks > 1) ? thg[jg] : 0u;
+        const uint32_t ent0 = (uint32_t)(dt * 32 + 4 * half) | ((uint32_t)colw << 24);   // entry of element 0; element e adds its row
+        if (first) {                                         // (1)
+            const float lo = __fsub_rn(q_share_max<MODE>(ok ? mx : 0.0f), E[ci]);
+            if (mayraise && lo >= lmin) tau[ci] = fmaxf(tau[ci], __fsub_rn(__fmul_rn(lo, FIC_Q_LEVEL), E[ci]));
+        }
         // candidate 0 = (block 0, copy 0): always evaluated (MODE 2: with its partner, copy 2)
         const bool cand0 = first && dt == 0 && half == 0 && ok && (jcol & ((1 << CSHIFT) - 1)) == 0;
         float mp = -1.0f;                                    // largest flagged test value on this lane
 #pragma unroll
         for (int e = 0; e < 16; e++) {
-            const int d = dt * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
             const float ve = val(acc, acc2, e);
-            const bool pe = (ok && d < A.Nd && ve > tau[ci]) || (e == 0 && cand0);
+            const bool pe = (ok && ve > tau[ci]) || (e == 0 && cand0);
             const unsigned long long be = __builtin_amdgcn_ballot_w64(pe);
             if (be == 0) continue;
             const int idx = qn + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(be >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)be, 0u));
             if (pe) {
-                myq[idx] = (uint32_t)d | ((uint32_t)colw << 24);
+                myq[idx] = ent0 + (uint32_t)((e & 3) + 8 * (e >> 2));
                 mp = fmaxf(mp, ve);
             }
             qn += __builtin_popcountll(be);
             st_pairs += (unsigned)__builtin_popcountll(be);
         }
-        if (((raise >> ci) & 1u) && mp >= 0.0f) {
-            const float lb = __fsub_rn(__fmul_rn(__fsub_rn(mp, E[ci]), FIC_Q_LEVEL), E[ci]);
-            atomicMax(&myTau[slot], f32_orderable(lb));
+        // (2): level of the best flagged entry, shared by the lanes of the range
+        const float lo2 = q_share_max<MODE>((mayraise && mp >= 0.0f) ? __fsub_rn(mp, E[ci]) : -1.0f);
+        if (mayraise && lo2 >= 0.0f) {
+            const float lb = __fsub_rn(__fmul_rn(lo2, FIC_Q_LEVEL), E[ci]);
+            tau[ci] = fmaxf(tau[ci], lb);
+            if (A.nchunks > 1 && lo2 >= lmin && half == 0 && (jcol & ((1 << CSHIFT) - 1)) == 0) atomicMax(&thg[jg], f32_orderable(lb));
         }
-        tau[ci] = f32_from_orderable(myTau[slot]);           // own update and those of the lanes sharing the range
-    };
-    // the chunk's first tile: seed theta from the tile's largest test value per range (see the header), then flag as usual
-    auto first_tile = [&](const v16f& acc, const v16f& acc2, int ci, int dt) __attribute__((always_inline)) {
-        const bool ok = (okbits >> ci) & 1u;
-        const int colw = ci * 32 + jcol;
-        const int slot = colw >> CSHIFT;
-        const float mx = FOLD ? max16_sum(acc, acc2) : max16_abs(acc);      // rows beyond N_d are zero fragments: value 0
-        if (ok) atomicMax(&myMax[slot], __float_as_uint(mx));   // >= 0: integer order == float order
-        const float lo = __fsub_rn(__uint_as_float(myMax[slot]), E[ci]);
-        if (((raise >> ci) & 1u) && lo >= 0.26f * (float)A.n) {
-            const float t0 = __fsub_rn(__fmul_rn(lo, FIC_Q_LEVEL), E[ci]);
-            tau[ci] = fmaxf(tau[ci], t0);
-            myTau[slot] = f32_orderable(tau[ci]);            // every lane of the slot computes the same value
-        }
-        flagged_tile(acc, acc2, mx, ci, dt, true);
+        if (mayraise && g != 0u) tau[ci] = fmaxf(tau[ci], f32_from_orderable(g));
     };
     // accumulator(s) of one 32x32 tile: FOLD: even part from steps [0, NK/2), odd part from steps [NK/2, NK)
     auto tile_mfma = [&](const v4i (&at)[NK], const v4i (&bt)[NK], v16f& acc, v16f& acc2) __attribute__((always_inline)) {
@@ -530,9 +531,8 @@ __global__ __launch_bounds__(256) void k_sweep_q(QArgs A)
     };
 
     // Fragment buffers in rotation.  PF = 2: a step computes on `ac`, finishes with the first tile of `an` (loaded during the
-    // previous step) and starts the loads of `a2n`, two domain tiles ahead (~1.75 steps to land); PF = 1 (where registers
+    // previous step) and starts the loads of `ld`, two domain tiles ahead (~1.75 steps to land); PF = 1 (where registers
     // are short): two buffers, the next tile's loads start at the top of the step.
-    constexpr int PF = (NK == 4 && !FOLD) ? 2 : 1;
     v4i a0[NK], a1[NK], a2[PF == 2 ? NK : 1];
 #pragma unroll
     for (int m = 0; m < NK; m++) a0[m] = pa[((size_t)dt0 * NK + m) * 64];
@@ -543,9 +543,9 @@ __global__ __launch_bounds__(256) void k_sweep_q(QArgs A)
     v16f acc, acc2 = zero;
     tile_mfma(a0, rb[0], acc, acc2);
 
-    // one domain tile (the fragment store has two spare tiles for the prefetch); `ld` receives tile dt + PF
-    auto step = [&](auto forced, int dt, const v4i (&ac)[NK], const v4i (&an)[NK], v4i (&ld)[NK]) __attribute__((always_inline)) {
-        constexpr bool FORCE = decltype(forced)::value;
+    // one domain tile; `ld` receives tile dt + PF (the fragment store has spare zero tiles behind the pool)
+    auto step = [&](int dt, const v4i (&ac)[NK], const v4i (&an)[NK], v4i (&ld)[NK]) __attribute__((always_inline)) {
+        const bool first = dt == dt0;
 #pragma unroll
         for (int m = 0; m < NK; m++) ld[m] = pa[((size_t)(dt + PF) * NK + m) * 64];
 #pragma unroll
@@ -554,55 +554,42 @@ __global__ __launch_bounds__(256) void k_sweep_q(QArgs A)
             v16f nacc, nacc2 = zero;
             if (ci + 1 < CTW) tile_mfma(ac, rb[ci + 1], nacc, nacc2);
             else tile_mfma(an, rb[0], nacc, nacc2);
-            if constexpr (FORCE) {
-                if (ci < nci) first_tile(acc, acc2, ci, dt);
-            } else {
-                const float mx = FOLD ? max16_sum(acc, acc2) : max16_abs(acc);
-                const bool hit = mx > tau[ci];
-                if constexpr (NK == 4 && !FOLD) {
-                    // M M v v v M v v v M v v v v v: the epilogue reads a tile whose last MFMA was issued >= 64 cycles ago
-                    __builtin_amdgcn_sched_group_barrier(0x8, 2, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x2, 3, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x2, 3, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x2, 3, 0);
-                } else if constexpr (NK == 4 && FOLD) {
-                    // 4 MFMAs (two 2-step accumulators), 16 adds + 8 max + compare: M M v*8 M v*8 M v*9
-                    __builtin_amdgcn_sched_group_barrier(0x8, 2, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x2, 8, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x2, 8, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x2, 9, 0);
-                }
-                if (__builtin_expect(__builtin_amdgcn_ballot_w64(hit) != 0, 0)) flagged_tile(acc, acc2, mx, ci, dt, false);
+            const float mx = FOLD ? max16_sum(acc, acc2) : max16_abs(acc);
+            const bool hit = mx > tau[ci];
+            if constexpr (NK == 4 && !FOLD) {
+                // M M v v v M v v v M v v v v v: the epilogue reads a tile whose last MFMA was issued >= 64 cycles ago
+                __builtin_amdgcn_sched_group_barrier(0x8, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x2, 3, 0);
+                __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x2, 3, 0);
+                __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x2, 3, 0);
+            } else if constexpr (NK == 4 && FOLD) {
+                // 4 MFMAs (two 2-step accumulators), 16 adds + 8 max + compare: M M v*8 M v*8 M v*9
+                __builtin_amdgcn_sched_group_barrier(0x8, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x2, 8, 0);
+                __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x2, 8, 0);
+                __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x2, 9, 0);
             }
+            // a chunk's first tile always takes the slow path: theta is seeded there and candidate 0 is queued
+            if (__builtin_expect((__builtin_amdgcn_ballot_w64(hit) != 0) | first, 0)) slow_tile(acc, acc2, mx, ci, dt, first);
             acc = nacc;
             if constexpr (FOLD) acc2 = nacc2;
         }
     };
-    int dt = dt0;
     if constexpr (PF == 2) {
-        step(std::true_type{}, dt, a0, a1, a2);
-        dt++;
-        for (; dt + 2 < dt1; dt += 3) {
-            step(std::false_type{}, dt, a1, a2, a0);
-            step(std::false_type{}, dt + 1, a2, a0, a1);
-            step(std::false_type{}, dt + 2, a0, a1, a2);
-        }
-        if (dt < dt1) {
-            step(std::false_type{}, dt, a1, a2, a0);
-            if (dt + 1 < dt1) step(std::false_type{}, dt + 1, a2, a0, a1);
+        for (int dt = dt0; dt < dt1; dt += 3) {
+            step(dt, a0, a1, a2);
+            step(dt + 1, a1, a2, a0);
+            step(dt + 2, a2, a0, a1);
         }
     } else {
-        step(std::true_type{}, dt, a0, a1, a1);
-        dt++;
-        for (; dt + 1 < dt1; dt += 2) {
-            step(std::false_type{}, dt, a1, a0, a0);
-            step(std::false_type{}, dt + 1, a0, a1, a1);
+        for (int dt = dt0; dt < dt1; dt += 2) {
+            step(dt, a0, a1, a1);
+            step(dt + 1, a1, a0, a0);
         }
-        if (dt < dt1) step(std::false_type{}, dt, a1, a0, a0);
     }
     flush();
     if (A.stats && lane == 0) {
@@ -620,36 +607,40 @@ int fic_q_ct(int B) { return 4 * fic_q_ctw(B * B / 16); }       // column tiles 
 // 0: 1 isometry; 1: 8 isometries, one column per copy; 2: 8 isometries folded into 4 columns per range block
 int fic_q_mode(int B, int n_iso) { return n_iso == 1 ? 0 : (B == 4 ? 1 : 2); }
 int fic_q_cols_per_range(int B, int n_iso) { const int m = fic_q_mode(B, n_iso); return m == 0 ? 1 : (m == 1 ? 8 : 4); }
+int fic_q_unroll(int B, int n_iso) { return fic_q_pf(B * B / 16, fic_q_mode(B, n_iso)) + 1; }
 
-int fic_launch_q_prep(const FicBuffers& b, void* poolQ, void* dflat, void* rngQ, void* rngE, void* rng_u8, const FicGeom& g,
-                      int ndtiles_alloc, int nct_alloc, int grp0, int ngrp, hipStream_t s)
+int fic_launch_q_prep(const FicBuffers& b, void* poolQ, void* dflat, void* rngQ, void* rngE, void* theta_g,
+                      const FicGeom& g, int ndtiles_alloc, int nct_alloc, int grp0, int ngrp, hipStream_t s)
 {
     const int mode = fic_q_mode(g.B, g.n_iso);
     hipLaunchKernelGGL(k_pool_q, dim3(ndtiles_alloc, g.planes), dim3(256), 0, s, (const uint8_t*)b.scaled, b.pool_pix,
                        b.pool_st, b.pool_var, b.pool_s64, (v4i*)poolQ, (uint32_t*)dflat, g, ndtiles_alloc, mode == 2 ? 1 : 0);
     FIC_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_range_q, dim3(ngrp, g.planes), dim3(256), 0, s, (const uint8_t*)b.gray, b.rng_st, (float*)rngE, b.key,
-                       (uint8_t*)rng_u8, (v4i*)rngQ, g, nct_alloc, grp0, mode);
+                       (uint32_t*)theta_g, (v4i*)rngQ, g, nct_alloc, grp0, mode);
     FIC_LAUNCH_CHECK();
     return 0;
 }
 
 int fic_launch_sweep_q(const FicBuffers& b, const void* poolQ, const void* dflat, const void* rngQ, const void* rngE,
-                       const void* rng_u8, const FicGeom& g, int ct_begin, int ct_end, int ndtiles, int ndtiles_alloc,
+                       void* theta_g, const FicGeom& g, int ct_begin, int ct_end, int ndtiles, int ndtiles_alloc,
                        int nct_alloc, int tiles_per_chunk, int nchunks, hipStream_t s, unsigned long long* stats)
 {
     QArgs A;
     A.stats = stats;
     A.poolQ = (const v4i*)poolQ; A.dflat = (const uint32_t*)dflat; A.pool_pix = b.pool_pix; A.pool_st = b.pool_st;
-    A.pool_s64 = b.pool_s64; A.rngQ = (const v4i*)rngQ; A.rng_u8 = (const uint8_t*)rng_u8; A.rng_st = b.rng_st;
-    A.rngE = (const float*)rngE; A.key = b.key;
-    A.Nd = g.Nd; A.Nd_pad = g.Nd_pad; A.Nr = g.Nr; A.Nr_pad = g.Nr_pad; A.n = g.n; A.lgn = g.lgn;
-    A.ndtiles = ndtiles; A.ndtiles_alloc = ndtiles_alloc; A.nct_alloc = nct_alloc;
+    A.pool_s64 = b.pool_s64; A.rngQ = (const v4i*)rngQ; A.gray = b.gray; A.rng_st = b.rng_st;
+    A.rngE = (const float*)rngE; A.key = b.key; A.theta_g = (uint32_t*)theta_g;
+    A.Nd = g.Nd; A.Nd_pad = g.Nd_pad; A.Nr = g.Nr; A.Nr_pad = g.Nr_pad; A.n = g.n; A.lgn = g.lgn; A.W = g.W; A.H = g.H; A.Rw = g.Rw;
+    const int unroll = fic_q_unroll(g.B, g.n_iso);
+    A.ndtiles = ndtiles; A.ndtiles_loop = (ndtiles + unroll - 1) / unroll * unroll; A.ndtiles_alloc = ndtiles_alloc; A.nct_alloc = nct_alloc;
     A.ct_begin = ct_begin; A.ct_end = ct_end; A.tiles_per_chunk = tiles_per_chunk; A.nchunks = nchunks;
     const int CT = fic_q_ct(g.B);
     A.nctg = (ct_end - ct_begin + CT - 1) / CT;
     A.planes = g.planes;
-    if (ct_begin + A.nctg * CT > nct_alloc || g.Nd >= (1 << 24) || ndtiles + 2 > ndtiles_alloc) return (int)hipErrorInvalidValue;
+    // the loop reads up to ndtiles_loop + prefetch distance tiles; chunks must be whole unrolled iterations
+    if (ct_begin + A.nctg * CT > nct_alloc || g.Nd >= (1 << 24) || A.ndtiles_loop + unroll > ndtiles_alloc || tiles_per_chunk % unroll)
+        return (int)hipErrorInvalidValue;
     dim3 grid((unsigned)(nchunks * g.planes) * (unsigned)A.nctg), block(256);
     const int mode = fic_q_mode(g.B, g.n_iso);
     if (g.B == 4 && mode == 0) hipLaunchKernelGGL((k_sweep_q<1, 0>), grid, block, 0, s, A);
