@@ -86,6 +86,14 @@ def lib():
         "fic_ctx_records_device_ptr": (C.c_int, [vp, C.POINTER(vp)]),
         "fic_ctx_collage_host": (C.c_int, [vp, i32p]),
         "fic_encode_rgb_argb": (C.c_int, [i32p] + [C.c_int] * 5 + [i32p, f32p, f32p, f32p, f32p, i32p, i32p]),
+        "fic_rgb_ctx_create": (vp, [C.c_int] * 6),
+        "fic_rgb_ctx_destroy": (None, [vp]),
+        "fic_rgb_ctx_set_argb_host": (C.c_int, [vp, i32p]),
+        "fic_rgb_ctx_set_argb_device": (C.c_int, [vp, vp]),
+        "fic_rgb_ctx_encode": (C.c_int, [vp, C.c_int, vp]),
+        "fic_rgb_ctx_sync": (C.c_int, [vp]),
+        "fic_rgb_ctx_get_results_host": (C.c_int, [vp, i32p, f32p, f32p, f32p, f32p, i32p, i32p]),
+        "fic_rgb_ctx_decode_host": (C.c_int, [vp, i32p, f32p, ip]),
         "fic_write_run_rgb": (C.c_int64, [i32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, u8p, C.c_int64]),
         "fic_decode_gray_run": (C.c_int, [u8p, C.c_int64, C.c_int, u8p, C.c_int64, ip, ip, f32p, ip]),
         "fic_ctx_decode_host": (C.c_int, [vp, u8p, f32p, ip]),
@@ -94,6 +102,7 @@ def lib():
         "fic_ctx_info": (C.c_int, [vp, ip]),
         "fic_ctx_sweep_stats": (C.c_int, [vp, C.POINTER(C.c_uint64), C.c_int]),
         "fic_debug_rccl_selftest": (C.c_int, [C.c_int]),
+        "fic_debug_decode_gray_run": (C.c_int, [u8p, C.c_int64, C.c_int, u8p, C.c_int64, f32p, ip, ip]),
         "fic_debug_sqrt_f64": (C.c_int, [C.c_int, C.c_uint32, C.c_uint32, C.POINTER(C.c_double)]),
         "fic_ctx_debug_pool_host": (C.c_int, [vp, u8p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), u8p]),
     }
@@ -213,6 +222,79 @@ def encode_rgb(argb, w, h, B, wK, device=0, want_collage=False):
     if want_collage:
         r["collage"] = col
     return r
+
+
+class RgbEncoder:
+    """Handle API of the joint-RGB path (fic_rgb_ctx_*): `planes` colour images of one geometry, device resident."""
+
+    def __init__(self, width, height, B, wK, planes=1, device=0):
+        L = lib()
+        self.width, self.height, self.B, self.wK, self.planes, self.device = width, height, B, wK, planes, device
+        Rw, Rh, Dw, Dh = geometry(width, height, B)
+        self.n_ranges = Rw * Rh
+        self._h = L.fic_rgb_ctx_create(device, width, height, B, wK, planes)
+        if not self._h:
+            raise FicError(L.fic_last_error_code() or -3, last_error())
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().fic_rgb_ctx_destroy(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_argb(self, argb):
+        """int32 [planes, H*W] numpy array (copied) or a torch CUDA int32 tensor of that many elements (used in place)."""
+        n = self.planes * self.width * self.height
+        if hasattr(argb, "data_ptr"):
+            if not argb.is_cuda or argb.element_size() != 4 or not argb.is_contiguous() or argb.numel() != n:
+                raise FicError(-3, "device input must be a contiguous int32 CUDA tensor [planes,H,W]")
+            self._keep = argb
+            check(lib().fic_rgb_ctx_set_argb_device(self._h, C.c_void_p(argb.data_ptr())))
+        else:
+            a = np.ascontiguousarray(argb, np.int32)
+            if a.size != n:
+                raise FicError(-3, "argb has the wrong number of pixels")
+            check(lib().fic_rgb_ctx_set_argb_host(self._h, ptr(a, C.c_int32)))
+
+    def encode(self, with_collage=False, stream=None):
+        s = 0 if stream is None else int(getattr(stream, "cuda_stream", stream))
+        check(lib().fic_rgb_ctx_encode(self._h, 1 if with_collage else 0, C.c_void_p(s)))
+        self._collage = bool(with_collage)
+
+    def sync(self):
+        check(lib().fic_rgb_ctx_sync(self._h))
+
+    def results(self):
+        P, N = self.planes, self.n_ranges
+        r = {"idx_local": np.zeros((P, N), np.int32), "a": np.zeros((P, N), np.float32), "bR": np.zeros((P, N), np.float32),
+             "bG": np.zeros((P, N), np.float32), "bB": np.zeros((P, N), np.float32), "qrows": np.zeros((P, N, 5), np.int32)}
+        col = np.zeros((P, self.height * self.width), np.int32) if getattr(self, "_collage", False) else None
+        check(lib().fic_rgb_ctx_get_results_host(self._h, ptr(r["idx_local"], C.c_int32), ptr(r["a"], C.c_float),
+                                                 ptr(r["bR"], C.c_float), ptr(r["bG"], C.c_float), ptr(r["bB"], C.c_float),
+                                                 ptr(r["qrows"], C.c_int32), ptr(col, C.c_int32)))
+        if col is not None:
+            r["collage"] = col
+        return r
+
+    def decode(self):
+        """decodeRGB from the context's quantised rows: (argb int32 [planes, H*W], avgError float32 [planes], iterations)."""
+        P = self.planes
+        out = np.zeros((P, self.height * self.width), np.int32)
+        avg = np.zeros(P, np.float32)
+        it = np.zeros(P, np.int32)
+        check(lib().fic_rgb_ctx_decode_host(self._h, ptr(out, C.c_int32), ptr(avg, C.c_float), ptr(it, C.c_int)))
+        return out, avg, it
 
 
 def write_run_rgb(qrows5, w, h, B, wK):

@@ -96,6 +96,8 @@ struct fic_ctx {
     int32_t* argb_stage = nullptr;   // staging for ARGB uploads
     int32_t* collage = nullptr;
     uint8_t* decoded = nullptr;      // decoder output image(s)
+    FicDecodeState* dec_state = nullptr;   // decoder loop state [planes] and per-pixel squared changes [planes][W*H]
+    uint32_t* dec_sq = nullptr;
     void* mfma_poolB = nullptr;      // opt-in matrix-core sweep: B fragments, A fragments, range constants
     void* mfma_rngA = nullptr;
     void* mfma_sw = nullptr;
@@ -136,7 +138,7 @@ int ctx_free_all(fic_ctx* c)
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
     c->ev.clear();
     if (c->own_stream) { (void)hipStreamDestroy(c->own_stream); c->own_stream = nullptr; }
-    void* ptrs[] = {c->gray_own, c->argb_stage, c->collage, c->decoded, c->mfma_poolB, c->mfma_rngA, c->mfma_sw, c->mfma_rconst, c->q_pool, c->q_flat, c->q_rng, c->q_E, c->q_thg, c->q_stats, c->d4_rng, c->d4_pool, c->b.scaled, c->b.pool_pix, c->b.pool_st, c->b.pool_var,
+    void* ptrs[] = {c->gray_own, c->argb_stage, c->collage, c->decoded, c->dec_state, c->dec_sq, c->mfma_poolB, c->mfma_rngA, c->mfma_sw, c->mfma_rconst, c->q_pool, c->q_flat, c->q_rng, c->q_E, c->q_thg, c->q_stats, c->d4_rng, c->d4_pool, c->b.scaled, c->b.pool_pix, c->b.pool_st, c->b.pool_var,
                     c->b.pool_s64, c->b.rng_pix, c->b.rng_st, c->b.key, c->o.idx_local, c->o.idx_global, c->o.iso,
                     c->o.a, c->o.b, c->o.err, c->o.qrows, c->o.records};
     for (void* p : ptrs)
@@ -858,15 +860,68 @@ int fic_ctx_debug_pool_host(fic_ctx* c, uint8_t* pix, uint32_t* sum, uint32_t* v
 }
 
 // ---- decoder (decodeGreyScale FC:356-421) ------------------------------------------------------
+namespace {
+// Device arenas of the stream decoders, kept between calls (the GUI decodes after every encode, CTL:178-179): one
+// allocation per (device, size class) instead of four hipMalloc/hipFree per call.  fic_release_cache() frees them.
+struct Arena {
+    int device = -1;
+    size_t bytes = 0;
+    char* base = nullptr;
+};
+std::mutex g_arena_mu;
+std::vector<Arena> g_arenas;
+constexpr size_t kArenaSlots = 4;
+
+int arena_take(int device, size_t bytes, Arena* out)
+{
+    {
+        std::lock_guard<std::mutex> lk(g_arena_mu);
+        for (size_t i = g_arenas.size(); i-- > 0;)
+            if (g_arenas[i].device == device && g_arenas[i].bytes >= bytes && g_arenas[i].bytes <= 2 * bytes + (1u << 20)) {
+                *out = g_arenas[i];
+                g_arenas.erase(g_arenas.begin() + (long)i);
+                return FIC_OK;
+            }
+    }
+    out->device = device;
+    out->bytes = bytes;
+    HIP_TRY(hipMalloc((void**)&out->base, bytes));
+    return FIC_OK;
+}
+void arena_give(const Arena& a)
+{
+    Arena evict;
+    {
+        std::lock_guard<std::mutex> lk(g_arena_mu);
+        g_arenas.push_back(a);
+        if (g_arenas.size() <= kArenaSlots) return;
+        evict = g_arenas.front();
+        g_arenas.erase(g_arenas.begin());
+    }
+    (void)hipSetDevice(evict.device);
+    (void)hipFree(evict.base);
+}
+void arena_release_all()
+{
+    std::vector<Arena> drop;
+    {
+        std::lock_guard<std::mutex> lk(g_arena_mu);
+        drop.swap(g_arenas);
+    }
+    for (const Arena& a : drop) { (void)hipSetDevice(a.device); (void)hipFree(a.base); }
+}
+size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+}  // namespace
+
 // Runs the reconstruction loop on the device.  Iterations are enqueued in groups of 8 and the
 // per-plane loop state is read back after each group (a converging decode takes 6-7 iterations),
 // so there is one host sync per group, none per iteration.
+//   d_state [planes], d_sqbuf u32 [planes][W*H]: scratch of the caller
 static int run_decode_loop(const FicGeom& g, uint8_t* d_scaled, uint8_t* d_image, const int32_t* d_qrows,
-                           const int32_t* d_iso, const float* avg_in, float* avg_out, int* iters_out, hipStream_t s)
+                           const int32_t* d_iso, FicDecodeState* d_state, uint32_t* d_sqbuf, const float* avg_in,
+                           float* avg_out, int* iters_out, int* seq_out, hipStream_t s)
 {
     const size_t P = (size_t)g.planes;
-    FicDecodeState* d_state = nullptr;
-    HIP_TRY(hipMalloc((void**)&d_state, P * sizeof(FicDecodeState)));
     std::vector<FicDecodeState> st(P);
     memset(st.data(), 0, P * sizeof(FicDecodeState));
     for (size_t p = 0; p < P; p++) st[p].avg = avg_in ? avg_in[p] : 0.0f;   // static avgError is never reset (FC:20)
@@ -875,7 +930,7 @@ static int run_decode_loop(const FicGeom& g, uint8_t* d_scaled, uint8_t* d_image
     if (e == hipSuccess) e = hipMemsetAsync(d_image, 128, P * g.W * g.H, s);        // generateGrayImage FC:1142-1148
     if (e != hipSuccess) rc = fail(FIC_E_HIP, "decode init: %s", hipGetErrorString(e));
     for (int counter = 0; rc == FIC_OK && counter < 50; counter++) {
-        if (fic_launch_decode_iteration(d_scaled, d_image, d_qrows, d_iso, d_state, counter, g, s)) {
+        if (fic_launch_decode_iteration(d_scaled, d_image, d_qrows, d_iso, d_state, d_sqbuf, counter, g, s)) {
             rc = fail(FIC_E_HIP, "decode iteration launch failed");
             break;
         }
@@ -888,7 +943,6 @@ static int run_decode_loop(const FicGeom& g, uint8_t* d_scaled, uint8_t* d_image
             if (all) break;
         }
     }
-    (void)hipFree(d_state);
     if (rc != FIC_OK) return rc;
     for (size_t p = 0; p < P; p++) {
         if (st[p].bad_index)
@@ -896,6 +950,7 @@ static int run_decode_loop(const FicGeom& g, uint8_t* d_scaled, uint8_t* d_image
                                         "(ArrayIndexOutOfBounds at FC:394 in the reference)", p);
         if (avg_out) avg_out[p] = st[p].avg_out;
         if (iters_out) iters_out[p] = st[p].iters;
+        if (seq_out) seq_out[p] = st[p].seq_sums;
     }
     return FIC_OK;
 }
@@ -909,24 +964,29 @@ int fic_ctx_decode_host(fic_ctx* c, uint8_t* gray_out, float* avg_error_out, int
     const FicGeom& g = c->g;
     size_t npix = (size_t)g.planes * g.W * g.H;
     if (!c->decoded) { int rc = dev_alloc(&c->decoded, npix); if (rc) return rc; }
+    if (!c->dec_state) { int rc = dev_alloc(&c->dec_state, (size_t)g.planes); if (rc) return rc; }
+    if (!c->dec_sq) { int rc = dev_alloc(&c->dec_sq, npix); if (rc) return rc; }
     HIP_TRY(hipStreamSynchronize(c->last_stream));
-    int rc = run_decode_loop(g, c->b.scaled, c->decoded, c->o.qrows, g.n_iso > 1 ? c->o.iso : nullptr, nullptr,
-                             avg_error_out, iterations_out, c->last_stream);
+    int rc = run_decode_loop(g, c->b.scaled, c->decoded, c->o.qrows, g.n_iso > 1 ? c->o.iso : nullptr, c->dec_state, c->dec_sq,
+                             nullptr, avg_error_out, iterations_out, nullptr, c->last_stream);
     if (rc) return rc;
     HIP_TRY(hipMemcpy(gray_out, c->decoded, npix, hipMemcpyDeviceToHost));
     return FIC_OK;
 }
 
-int fic_decode_gray_run(const uint8_t* run, int64_t len, int device, uint8_t* gray_out, int64_t capacity, int* w_out,
-                        int* h_out, float* avg_error_io, int* iterations)
+static int32_t run_be32(const uint8_t* run, int64_t off)
+{
+    return (int32_t)(((uint32_t)run[off] << 24) | ((uint32_t)run[off + 1] << 16) | ((uint32_t)run[off + 2] << 8) |
+                     (uint32_t)run[off + 3]);
+}
+
+static int decode_gray_run_impl(const uint8_t* run, int64_t len, int device, uint8_t* gray_out, int64_t capacity, int* w_out,
+                                int* h_out, float* avg_error_io, int* iterations, int* seq_sums)
 {
     if (!run || len < 20) return fail(FIC_E_ARGUMENT, "fic_decode_gray_run: stream shorter than the 20-byte header");
-    auto be = [&](int64_t off) {
-        return (int32_t)(((uint32_t)run[off] << 24) | ((uint32_t)run[off + 1] << 16) | ((uint32_t)run[off + 2] << 8) |
-                         (uint32_t)run[off + 3]);
-    };
-    if (be(0) != 0) return fail(FIC_E_NOT_GREY, "fic_decode_gray_run: isRGB = %d (FC:548-552 dispatches to decodeRGB)", be(0));
-    const int w = be(4), h = be(8), B = be(12), wK = be(16);
+    if (run_be32(run, 0) != 0)
+        return fail(FIC_E_NOT_GREY, "fic_decode_gray_run: isRGB = %d (FC:548-552 dispatches to decodeRGB)", run_be32(run, 0));
+    const int w = run_be32(run, 4), h = run_be32(run, 8), B = run_be32(run, 12), wK = run_be32(run, 16);
     FicGeom g;
     int rc = make_geometry(w, h, B, wK, 1, 1, &g);
     if (rc) return rc;
@@ -940,23 +1000,40 @@ int fic_decode_gray_run(const uint8_t* run, int64_t len, int device, uint8_t* gr
     if (ndev <= 0 || device < 0 || device >= ndev) return fail(FIC_E_NO_DEVICE, "no HIP device %d (this library has no CPU path)", device);
     HIP_TRY(hipSetDevice(device));
     std::vector<int32_t> q((size_t)g.Nr * 3);
-    for (size_t i = 0; i < q.size(); i++) q[i] = be(20 + 4 * (int64_t)i);          // FC:372-374
-    uint8_t *d_scaled = nullptr, *d_image = nullptr;
-    int32_t* d_q = nullptr;
-    hipError_t e = hipMalloc((void**)&d_scaled, (size_t)g.Ws * g.Hs);
-    if (e == hipSuccess) e = hipMalloc((void**)&d_image, (size_t)w * h);
-    if (e == hipSuccess) e = hipMalloc((void**)&d_q, q.size() * 4);
-    if (e == hipSuccess) e = hipMemcpy(d_q, q.data(), q.size() * 4, hipMemcpyHostToDevice);
+    for (size_t i = 0; i < q.size(); i++) q[i] = run_be32(run, 20 + 4 * (int64_t)i);          // FC:372-374
+    const size_t npix = (size_t)w * h;
+    const size_t o_scaled = 0, o_image = o_scaled + align256((size_t)g.Ws * g.Hs), o_q = o_image + align256(npix),
+                 o_state = o_q + align256(q.size() * 4), o_sq = o_state + align256(sizeof(FicDecodeState)),
+                 total = o_sq + align256(npix * 4);
+    Arena ar;
+    rc = arena_take(device, total, &ar);
+    if (rc) return rc;
+    hipError_t e = hipMemcpy(ar.base + o_q, q.data(), q.size() * 4, hipMemcpyHostToDevice);
     if (e != hipSuccess) rc = fail(FIC_E_HIP, "fic_decode_gray_run: %s", hipGetErrorString(e));
     float avg = avg_error_io ? *avg_error_io : 0.0f;
-    if (rc == FIC_OK) rc = run_decode_loop(g, d_scaled, d_image, d_q, nullptr, &avg, &avg, iterations, nullptr);
+    if (rc == FIC_OK)
+        rc = run_decode_loop(g, (uint8_t*)(ar.base + o_scaled), (uint8_t*)(ar.base + o_image), (const int32_t*)(ar.base + o_q), nullptr,
+                             (FicDecodeState*)(ar.base + o_state), (uint32_t*)(ar.base + o_sq), &avg, &avg, iterations, seq_sums, nullptr);
     if (rc == FIC_OK) {
-        e = hipMemcpy(gray_out, d_image, (size_t)w * h, hipMemcpyDeviceToHost);
+        e = hipMemcpy(gray_out, ar.base + o_image, npix, hipMemcpyDeviceToHost);
         if (e != hipSuccess) rc = fail(FIC_E_HIP, "fic_decode_gray_run: %s", hipGetErrorString(e));
     }
     if (rc == FIC_OK && avg_error_io) *avg_error_io = avg;
-    (void)hipFree(d_scaled); (void)hipFree(d_image); (void)hipFree(d_q);
+    arena_give(ar);
     return rc;
+}
+
+int fic_decode_gray_run(const uint8_t* run, int64_t len, int device, uint8_t* gray_out, int64_t capacity, int* w_out,
+                        int* h_out, float* avg_error_io, int* iterations)
+{
+    return decode_gray_run_impl(run, len, device, gray_out, capacity, w_out, h_out, avg_error_io, iterations, nullptr);
+}
+
+// Test hook: fic_decode_gray_run that also reports how many iterations needed the sequential (Java-order) float sum.
+int fic_debug_decode_gray_run(const uint8_t* run, int64_t len, int device, uint8_t* gray_out, int64_t capacity,
+                              float* avg_error_io, int* iterations, int* seq_sums)
+{
+    return decode_gray_run_impl(run, len, device, gray_out, capacity, nullptr, nullptr, avg_error_io, iterations, seq_sums);
 }
 
 // ---- decodeRGB (FC:430-508) -----------------------------------------------------------------------
@@ -964,12 +1041,8 @@ int fic_decode_rgb_run(const uint8_t* run, int64_t len, int device, int32_t* arg
                        int* w_out, int* h_out, float* avg_error_io, int* iterations)
 {
     if (!run || len < 20) return fail(FIC_E_ARGUMENT, "fic_decode_rgb_run: stream shorter than the 20-byte header");
-    auto be = [&](int64_t off) {
-        return (int32_t)(((uint32_t)run[off] << 24) | ((uint32_t)run[off + 1] << 16) | ((uint32_t)run[off + 2] << 8) |
-                         (uint32_t)run[off + 3]);
-    };
-    if (be(0) == 0) return fail(FIC_E_ARGUMENT, "fic_decode_rgb_run: isRGB = 0 (FC:548-550 dispatches to decodeGreyScale)");
-    const int w = be(4), h = be(8), B = be(12), wK = be(16);
+    if (run_be32(run, 0) == 0) return fail(FIC_E_ARGUMENT, "fic_decode_rgb_run: isRGB = 0 (FC:548-550 dispatches to decodeGreyScale)");
+    const int w = run_be32(run, 4), h = run_be32(run, 8), B = run_be32(run, 12), wK = run_be32(run, 16);
     FicGeom g;
     int rc = make_geometry(w, h, B, wK, 1, 1, &g);
     if (rc) return rc;
@@ -983,24 +1056,29 @@ int fic_decode_rgb_run(const uint8_t* run, int64_t len, int device, int32_t* arg
     if (ndev <= 0 || device < 0 || device >= ndev) return fail(FIC_E_NO_DEVICE, "no HIP device %d (this library has no CPU path)", device);
     HIP_TRY(hipSetDevice(device));
     std::vector<int32_t> q((size_t)g.Nr * 5);
-    for (size_t i = 0; i < q.size(); i++) q[i] = be(20 + 4 * (int64_t)i);          // FC:446-450
+    for (size_t i = 0; i < q.size(); i++) q[i] = run_be32(run, 20 + 4 * (int64_t)i);          // FC:446-450
     const size_t npix = (size_t)w * h;
     std::vector<int32_t> init(npix, (int32_t)0xff808080u);                          // generateGrayImage FC:1142-1148
-    int32_t *d_scaled = nullptr, *d_image = nullptr, *d_q = nullptr;
-    FicDecodeState* d_state = nullptr;
+    const size_t o_scaled = 0, o_image = o_scaled + align256((size_t)g.Ws * g.Hs * 4), o_q = o_image + align256(npix * 4),
+                 o_state = o_q + align256(q.size() * 4), o_sq = o_state + align256(sizeof(FicDecodeState)),
+                 total = o_sq + align256(npix * 4);
+    Arena ar;
+    rc = arena_take(device, total, &ar);
+    if (rc) return rc;
+    int32_t* d_scaled = (int32_t*)(ar.base + o_scaled);
+    int32_t* d_image = (int32_t*)(ar.base + o_image);
+    int32_t* d_q = (int32_t*)(ar.base + o_q);
+    FicDecodeState* d_state = (FicDecodeState*)(ar.base + o_state);
+    uint32_t* d_sq = (uint32_t*)(ar.base + o_sq);
     FicDecodeState st;
     memset(&st, 0, sizeof(st));
     st.avg = avg_error_io ? *avg_error_io : 0.0f;
-    hipError_t e = hipMalloc((void**)&d_scaled, (size_t)g.Ws * g.Hs * 4);
-    if (e == hipSuccess) e = hipMalloc((void**)&d_image, npix * 4);
-    if (e == hipSuccess) e = hipMalloc((void**)&d_q, q.size() * 4);
-    if (e == hipSuccess) e = hipMalloc((void**)&d_state, sizeof(st));
-    if (e == hipSuccess) e = hipMemcpy(d_q, q.data(), q.size() * 4, hipMemcpyHostToDevice);
+    hipError_t e = hipMemcpy(d_q, q.data(), q.size() * 4, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(d_image, init.data(), npix * 4, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(d_state, &st, sizeof(st), hipMemcpyHostToDevice);
     if (e != hipSuccess) rc = fail(FIC_E_HIP, "fic_decode_rgb_run: %s", hipGetErrorString(e));
     for (int counter = 0; rc == FIC_OK && counter < 50; counter++) {
-        if (fic_launch_decode_iteration_rgb(d_scaled, d_image, d_q, d_state, counter, g, nullptr)) {
+        if (fic_launch_decode_iteration_rgb(d_scaled, d_image, d_q, d_state, d_sq, counter, g, nullptr)) {
             rc = fail(FIC_E_HIP, "decodeRGB iteration launch failed");
             break;
         }
@@ -1020,63 +1098,257 @@ int fic_decode_rgb_run(const uint8_t* run, int64_t len, int device, int32_t* arg
         if (avg_error_io) *avg_error_io = st.avg_out;
         if (iterations) *iterations = st.iters;
     }
-    (void)hipFree(d_scaled); (void)hipFree(d_image); (void)hipFree(d_q); (void)hipFree(d_state);
+    arena_give(ar);
     return rc;
 }
 
 // ---- joint-RGB encode (encodeRGB FC:171-219) -----------------------------------------------------
-namespace {
-// Working set of the last one-shot RGB geometry: the GUI re-encodes the same image on every slider move
-// (RLEAppController.java:125-145), and 16 hipMalloc/hipFree cost more than a windowed search.  One slot; a call with
-// another geometry (or device) replaces it; fic_release_cache() frees it.
-struct RgbSet {
-    int device = -1, w = 0, h = 0, B = 0, wK = 0;
-    FicRgbBuffers b{};
-    FicRgbOutputs o{};
-    int32_t* collage = nullptr;
-    void free_all()
-    {
-        if (device >= 0) (void)hipSetDevice(device);
-        void* ptrs[] = {b.argb, b.scaled, b.pool_sum, b.pool_cf, b.pool_st, b.rng_t, b.rng_st, b.key, o.idx_local,
-                        o.idx_global, o.a, o.bR, o.bG, o.bB, o.qrows, collage};
-        for (void* p : ptrs)
-            if (p) (void)hipFree(p);
-        memset(&b, 0, sizeof(b));
-        memset(&o, 0, sizeof(o));
-        collage = nullptr;
-        device = -1;
-    }
+// A context owns the device working set of `planes` colour images of one geometry (config-5 style batches; the one-shot
+// entry keeps a few single-image contexts).  The kernels are per image: a batch is their launch sequence per plane on the
+// caller's stream.  The covariance sums stay sequential f32 in the reference's order (FC:781-792: they exceed 2^24).
+struct fic_rgb_ctx {
+    int device = 0;
+    FicGeom g;
+    int32_t* argb_own = nullptr;     // context-owned input copy
+    const int32_t* argb = nullptr;   // input in use (own copy or the caller's device pointer)
+    int32_t* scaled = nullptr;       // per plane: [H/2][W/2]
+    uint16_t* pool_sum = nullptr;    // [N_d][n]
+    float* pool_cf = nullptr;        // [N_d][n] (full search at B = 4 / 8)
+    FicRgbDomStat* pool_st = nullptr;
+    int16_t* rng_t = nullptr;
+    FicRgbRngStat* rng_st = nullptr;
+    unsigned long long* key = nullptr;
+    int32_t *idx_local = nullptr, *idx_global = nullptr, *qrows = nullptr, *collage = nullptr;
+    float *a = nullptr, *bR = nullptr, *bG = nullptr, *bB = nullptr;
+    int32_t* dec_image = nullptr;    // decoder: image, scaled image, state, per-pixel squared changes (one plane at a time)
+    int32_t* dec_scaled = nullptr;
+    FicDecodeState* dec_state = nullptr;
+    uint32_t* dec_sq = nullptr;
+    bool have_input = false, encoded_any = false, have_collage = false;
+    hipStream_t last_stream = nullptr;
+    std::mutex mu;
 };
-std::mutex g_rgb_mu;
-RgbSet* g_rgb_set = nullptr;
 
-int rgb_set_alloc(RgbSet* r, const FicGeom& g, int device, int w, int h, int B, int wK)
+namespace {
+void rgb_free_all(fic_rgb_ctx* c)
 {
-    const size_t npix = (size_t)w * h, nr = (size_t)g.Nr, nd = (size_t)g.Nd, n = (size_t)g.n;
-    hipError_t e = hipSuccess;
-    auto M = [&](void** p, size_t bytes) { if (e == hipSuccess) e = hipMalloc(p, bytes); };
-    r->device = device; r->w = w; r->h = h; r->B = B; r->wK = wK;
-    M((void**)&r->b.argb, npix * 4);
-    M((void**)&r->b.scaled, (size_t)g.Ws * g.Hs * 4);
-    M((void**)&r->b.pool_sum, nd * n * 2);
-    if (g.full && g.B <= 8) M((void**)&r->b.pool_cf, nd * n * 4);      // fast full-search sweep (k_sweep_rgb_fast)
-    M((void**)&r->b.pool_st, nd * sizeof(FicRgbDomStat));
-    M((void**)&r->b.rng_t, nr * n * 2);
-    M((void**)&r->b.rng_st, nr * sizeof(FicRgbRngStat));
-    M((void**)&r->b.key, nr * 8);
-    M((void**)&r->o.idx_local, nr * 4);
-    M((void**)&r->o.idx_global, nr * 4);
-    M((void**)&r->o.a, nr * 4);
-    M((void**)&r->o.bR, nr * 4);
-    M((void**)&r->o.bG, nr * 4);
-    M((void**)&r->o.bB, nr * 4);
-    M((void**)&r->o.qrows, nr * 20);
-    M((void**)&r->collage, npix * 4);
-    if (e != hipSuccess) {
-        r->free_all();
-        return fail(FIC_E_HIP, "fic_encode_rgb_argb: %s", hipGetErrorString(e));
+    (void)hipSetDevice(c->device);
+    void* ptrs[] = {c->argb_own, c->scaled, c->pool_sum, c->pool_cf, c->pool_st, c->rng_t, c->rng_st, c->key, c->idx_local,
+                    c->idx_global, c->qrows, c->collage, c->a, c->bR, c->bG, c->bB, c->dec_image, c->dec_scaled, c->dec_state, c->dec_sq};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+}
+// buffers of plane p as the per-image kernels expect them
+void rgb_plane(const fic_rgb_ctx* c, int p, FicRgbBuffers* b, FicRgbOutputs* o)
+{
+    const FicGeom& g = c->g;
+    const size_t P = (size_t)p, nd = (size_t)g.Nd, nr = (size_t)g.Nr, n = (size_t)g.n;
+    b->argb = const_cast<int32_t*>(c->argb) + P * g.W * g.H;
+    b->scaled = c->scaled + P * g.Ws * g.Hs;
+    b->pool_sum = c->pool_sum + P * nd * n;
+    b->pool_cf = c->pool_cf ? c->pool_cf + P * nd * n : nullptr;
+    b->pool_st = c->pool_st + P * nd;
+    b->rng_t = c->rng_t + P * nr * n;
+    b->rng_st = c->rng_st + P * nr;
+    b->key = c->key + P * nr;
+    o->idx_local = c->idx_local + P * nr;
+    o->idx_global = c->idx_global + P * nr;
+    o->a = c->a + P * nr;
+    o->bR = c->bR + P * nr;
+    o->bG = c->bG + P * nr;
+    o->bB = c->bB + P * nr;
+    o->qrows = c->qrows + P * nr * 5;
+}
+// idle single-image contexts of the one-shot RGB entry, most recently used last
+std::mutex g_rgb_mu;
+std::vector<fic_rgb_ctx*> g_rgb_cache;
+}  // namespace
+
+fic_rgb_ctx* fic_rgb_ctx_create(int device, int w, int h, int B, int wK, int planes)
+{
+    FicGeom g;
+    if (make_geometry(w, h, B, wK, 1, planes, &g)) return nullptr;
+    int ndev = fic_device_count();
+    if (ndev <= 0) { fail(FIC_E_NO_DEVICE, "no HIP device visible (this library has no CPU path)"); return nullptr; }
+    if (device < 0 || device >= ndev) { fail(FIC_E_NO_DEVICE, "device %d out of range (0..%d)", device, ndev - 1); return nullptr; }
+    if (hipSetDevice(device) != hipSuccess) { fail(FIC_E_HIP, "hipSetDevice(%d) failed", device); return nullptr; }
+    fic_rgb_ctx* c = new fic_rgb_ctx();
+    c->device = device;
+    c->g = g;
+    const size_t P = (size_t)planes, npix = (size_t)w * h, nr = (size_t)g.Nr, nd = (size_t)g.Nd, n = (size_t)g.n;
+    int rc = FIC_OK;
+    auto A = [&](int r) { if (rc == FIC_OK) rc = r; };
+    A(dev_alloc(&c->scaled, P * g.Ws * g.Hs));
+    A(dev_alloc(&c->pool_sum, P * nd * n));
+    if (g.full && g.B <= 8) A(dev_alloc(&c->pool_cf, P * nd * n));      // fast full-search sweep (k_sweep_rgb_fast)
+    A(dev_alloc(&c->pool_st, P * nd));
+    A(dev_alloc(&c->rng_t, P * nr * n));
+    A(dev_alloc(&c->rng_st, P * nr));
+    A(dev_alloc(&c->key, P * nr));
+    A(dev_alloc(&c->idx_local, P * nr));
+    A(dev_alloc(&c->idx_global, P * nr));
+    A(dev_alloc(&c->a, P * nr));
+    A(dev_alloc(&c->bR, P * nr));
+    A(dev_alloc(&c->bG, P * nr));
+    A(dev_alloc(&c->bB, P * nr));
+    A(dev_alloc(&c->qrows, P * nr * 5));
+    A(dev_alloc(&c->collage, P * npix));
+    if (rc != FIC_OK) {
+        rgb_free_all(c);
+        delete c;
+        return nullptr;
+    }
+    return c;
+}
+
+void fic_rgb_ctx_destroy(fic_rgb_ctx* c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipDeviceSynchronize();
+    rgb_free_all(c);
+    delete c;
+}
+
+int fic_rgb_ctx_set_argb_host(fic_rgb_ctx* c, const int32_t* argb)
+{
+    if (!c || !argb) return fail(FIC_E_ARGUMENT, "fic_rgb_ctx_set_argb_host: null argument");
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t npix = (size_t)c->g.planes * c->g.W * c->g.H;
+    if (!c->argb_own) { int rc = dev_alloc(&c->argb_own, npix); if (rc) return rc; }
+    HIP_TRY(hipStreamSynchronize(c->last_stream));     // a previous encode may still read the copy
+    HIP_TRY(hipMemcpy(c->argb_own, argb, npix * sizeof(int32_t), hipMemcpyHostToDevice));
+    c->argb = c->argb_own;
+    c->have_input = true;
+    return FIC_OK;
+}
+
+int fic_rgb_ctx_set_argb_device(fic_rgb_ctx* c, const void* dev_argb)
+{
+    if (!c || !dev_argb) return fail(FIC_E_ARGUMENT, "fic_rgb_ctx_set_argb_device: null argument");
+    std::lock_guard<std::mutex> lk(c->mu);
+    c->argb = (const int32_t*)dev_argb;
+    c->have_input = true;
+    return FIC_OK;
+}
+
+int fic_rgb_ctx_encode(fic_rgb_ctx* c, int with_collage, void* hip_stream)
+{
+    if (!c) return fail(FIC_E_ARGUMENT, "fic_rgb_ctx_encode: null context");
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (!c->have_input) return fail(FIC_E_STATE, "fic_rgb_ctx_encode: no input image set");
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t s = (hipStream_t)hip_stream;
+    c->last_stream = s;
+    const FicGeom& g = c->g;
+    FicGeom g1 = g;
+    g1.planes = 1;
+    for (int p = 0; p < g.planes; p++) {
+        FicRgbBuffers b;
+        FicRgbOutputs o;
+        rgb_plane(c, p, &b, &o);
+        if (fic_launch_rgb_encode(b, o, with_collage ? c->collage + (size_t)p * g.W * g.H : nullptr, g1, s))
+            return fail(FIC_E_HIP, "RGB kernel launch failed (plane %d)", p);
+    }
+    c->encoded_any = true;
+    c->have_collage = with_collage != 0;
+    return FIC_OK;
+}
+
+int fic_rgb_ctx_sync(fic_rgb_ctx* c)
+{
+    if (!c) return fail(FIC_E_ARGUMENT, "fic_rgb_ctx_sync: null context");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->last_stream));
+    return FIC_OK;
+}
+
+int fic_rgb_ctx_get_results_host(fic_rgb_ctx* c, int32_t* idx_local, float* a, float* bR, float* bG, float* bB, int32_t* qrows5,
+                                 int32_t* collage_argb)
+{
+    if (!c) return fail(FIC_E_ARGUMENT, "fic_rgb_ctx_get_results_host: null context");
+    if (!c->encoded_any) return fail(FIC_E_STATE, "fic_rgb_ctx_get_results_host: nothing encoded yet");
+    if (collage_argb && !c->have_collage) return fail(FIC_E_STATE, "fic_rgb_ctx_get_results_host: the last encode built no collage");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->last_stream));
+    const size_t n = (size_t)c->g.planes * c->g.Nr;
+    if (idx_local) HIP_TRY(hipMemcpy(idx_local, c->idx_local, n * 4, hipMemcpyDeviceToHost));
+    if (a) HIP_TRY(hipMemcpy(a, c->a, n * 4, hipMemcpyDeviceToHost));
+    if (bR) HIP_TRY(hipMemcpy(bR, c->bR, n * 4, hipMemcpyDeviceToHost));
+    if (bG) HIP_TRY(hipMemcpy(bG, c->bG, n * 4, hipMemcpyDeviceToHost));
+    if (bB) HIP_TRY(hipMemcpy(bB, c->bB, n * 4, hipMemcpyDeviceToHost));
+    if (qrows5) HIP_TRY(hipMemcpy(qrows5, c->qrows, n * 20, hipMemcpyDeviceToHost));
+    if (collage_argb) HIP_TRY(hipMemcpy(collage_argb, c->collage, (size_t)c->g.planes * c->g.W * c->g.H * 4, hipMemcpyDeviceToHost));
+    return FIC_OK;
+}
+
+// decodeRGB (FC:430-508) from the context's quantised rows, plane by plane, everything device resident
+int fic_rgb_ctx_decode_host(fic_rgb_ctx* c, int32_t* argb_out, float* avg_error_out, int* iterations_out)
+{
+    if (!c || !argb_out) return fail(FIC_E_ARGUMENT, "fic_rgb_ctx_decode_host: null argument");
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (!c->encoded_any) return fail(FIC_E_STATE, "fic_rgb_ctx_decode_host: nothing encoded yet");
+    HIP_TRY(hipSetDevice(c->device));
+    const FicGeom& g = c->g;
+    FicGeom g1 = g;
+    g1.planes = 1;
+    const size_t npix = (size_t)g.W * g.H;
+    if (!c->dec_image) { int rc = dev_alloc(&c->dec_image, npix); if (rc) return rc; }
+    if (!c->dec_scaled) { int rc = dev_alloc(&c->dec_scaled, (size_t)g.Ws * g.Hs); if (rc) return rc; }
+    if (!c->dec_state) { int rc = dev_alloc(&c->dec_state, 1); if (rc) return rc; }
+    if (!c->dec_sq) { int rc = dev_alloc(&c->dec_sq, npix); if (rc) return rc; }
+    hipStream_t s = c->last_stream;
+    std::vector<int32_t> init(npix, (int32_t)0xff808080u);                          // generateGrayImage FC:1142-1148
+    for (int p = 0; p < g.planes; p++) {
+        FicDecodeState st;
+        memset(&st, 0, sizeof(st));
+        HIP_TRY(hipMemcpyAsync(c->dec_image, init.data(), npix * 4, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(c->dec_state, &st, sizeof(st), hipMemcpyHostToDevice, s));
+        for (int counter = 0; counter < 50; counter++) {
+            if (fic_launch_decode_iteration_rgb(c->dec_scaled, c->dec_image, c->qrows + (size_t)p * g.Nr * 5, c->dec_state, c->dec_sq,
+                                                counter, g1, s))
+                return fail(FIC_E_HIP, "decodeRGB iteration launch failed");
+            if ((counter & 7) == 7 || counter == 49) {
+                HIP_TRY(hipMemcpyAsync(&st, c->dec_state, sizeof(st), hipMemcpyDeviceToHost, s));
+                HIP_TRY(hipStreamSynchronize(s));
+                if (st.done) break;
+            }
+        }
+        if (st.bad_index) return fail(FIC_E_ARGUMENT, "decodeRGB: a codebook row of plane %d points outside the domain pool", p);
+        HIP_TRY(hipMemcpy(argb_out + (size_t)p * npix, c->dec_image, npix * 4, hipMemcpyDeviceToHost));
+        if (avg_error_out) avg_error_out[p] = st.avg_out;
+        if (iterations_out) iterations_out[p] = st.iters;
     }
     return FIC_OK;
+}
+
+namespace {
+fic_rgb_ctx* rgb_cache_take(int device, int w, int h, int B, int wK)
+{
+    std::lock_guard<std::mutex> lk(g_rgb_mu);
+    for (size_t i = g_rgb_cache.size(); i-- > 0;) {
+        fic_rgb_ctx* c = g_rgb_cache[i];
+        const FicGeom& g = c->g;
+        if (c->device == device && g.W == w && g.H == h && g.B == B && g.wK == wK && g.planes == 1) {
+            g_rgb_cache.erase(g_rgb_cache.begin() + (long)i);
+            return c;
+        }
+    }
+    return nullptr;
+}
+void rgb_cache_give(fic_rgb_ctx* c)
+{
+    fic_rgb_ctx* evict = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_rgb_mu);
+        g_rgb_cache.push_back(c);
+        if (g_rgb_cache.size() > 4) {
+            evict = g_rgb_cache.front();
+            g_rgb_cache.erase(g_rgb_cache.begin());
+        }
+    }
+    if (evict) fic_rgb_ctx_destroy(evict);
 }
 }  // namespace
 
@@ -1084,61 +1356,19 @@ int fic_encode_rgb_argb(const int32_t* argb, int w, int h, int B, int wK, int de
                         float* bR, float* bG, float* bB, int32_t* qrows5, int32_t* collage_argb)
 {
     if (!argb || !idx_local || !a || !bR || !bG || !bB) return fail(FIC_E_ARGUMENT, "fic_encode_rgb_argb: null argument");
-    FicGeom g;
-    int rc = make_geometry(w, h, B, wK, 1, 1, &g);
-    if (rc) return rc;
-    int ndev = fic_device_count();
-    if (ndev <= 0 || device < 0 || device >= ndev) return fail(FIC_E_NO_DEVICE, "no HIP device %d (this library has no CPU path)", device);
-    HIP_TRY(hipSetDevice(device));
-    // take the cached working set if it fits, else build one (concurrent callers each get their own)
-    RgbSet* r = nullptr;
-    {
-        std::lock_guard<std::mutex> lk(g_rgb_mu);
-        if (g_rgb_set && g_rgb_set->device == device && g_rgb_set->w == w && g_rgb_set->h == h && g_rgb_set->B == B &&
-            g_rgb_set->wK == wK) {
-            r = g_rgb_set;
-            g_rgb_set = nullptr;
-        }
-    }
-    if (!r) {
-        r = new RgbSet();
-        rc = rgb_set_alloc(r, g, device, w, h, B, wK);
-        if (rc) { delete r; return rc; }
-    }
-    const size_t npix = (size_t)w * h, nr = (size_t)g.Nr;
-    hipError_t e = hipMemcpy(r->b.argb, argb, npix * 4, hipMemcpyHostToDevice);
-    if (e != hipSuccess) rc = fail(FIC_E_HIP, "fic_encode_rgb_argb: %s", hipGetErrorString(e));
-    if (rc == FIC_OK && fic_launch_rgb_encode(r->b, r->o, collage_argb ? r->collage : nullptr, g, nullptr))
-        rc = fail(FIC_E_HIP, "RGB kernel launch failed");
-    auto D = [&](void* dst, const void* src, size_t bytes) {
-        if (rc == FIC_OK && dst) {
-            hipError_t e2 = hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost);
-            if (e2 != hipSuccess) rc = fail(FIC_E_HIP, "fic_encode_rgb_argb: %s", hipGetErrorString(e2));
-        }
-    };
-    D(idx_local, r->o.idx_local, nr * 4);
-    D(a, r->o.a, nr * 4);
-    D(bR, r->o.bR, nr * 4);
-    D(bG, r->o.bG, nr * 4);
-    D(bB, r->o.bB, nr * 4);
-    D(qrows5, r->o.qrows, nr * 20);
-    D(collage_argb, r->collage, npix * 4);
-    RgbSet* drop = nullptr;
-    if (rc == FIC_OK) {
-        std::lock_guard<std::mutex> lk(g_rgb_mu);
-        drop = g_rgb_set;
-        g_rgb_set = r;
-    } else {
-        drop = r;
-    }
-    if (drop) {
-        const std::string keep = g_err;
-        const int keep_code = g_err_code;
-        drop->free_all();
-        delete drop;
-        g_err = keep;
-        g_err_code = keep_code;
-    }
+    // the GUI re-encodes the same image on every slider move (CTL:125-145): keep the last few working sets
+    fic_rgb_ctx* c = rgb_cache_take(device, w, h, B, wK);
+    if (!c) c = fic_rgb_ctx_create(device, w, h, B, wK, 1);
+    if (!c) return g_err_code ? g_err_code : FIC_E_HIP;   // fic_rgb_ctx_create recorded why
+    int rc = fic_rgb_ctx_set_argb_host(c, argb);
+    if (rc == FIC_OK) rc = fic_rgb_ctx_encode(c, collage_argb ? 1 : 0, nullptr);
+    if (rc == FIC_OK) rc = fic_rgb_ctx_get_results_host(c, idx_local, a, bR, bG, bB, qrows5, collage_argb);
+    const std::string keep = g_err;
+    const int keep_code = g_err_code;
+    if (rc == FIC_OK) rgb_cache_give(c);
+    else fic_rgb_ctx_destroy(c);
+    g_err = keep;
+    g_err_code = keep_code;
     return rc;
 }
 
@@ -1188,17 +1418,14 @@ void fic_release_cache(void)
         drop.swap(g_cache);
     }
     for (fic_ctx* c : drop) fic_ctx_destroy(c);
-    RgbSet* r = nullptr;
+    std::vector<fic_rgb_ctx*> drop_rgb;
     {
         std::lock_guard<std::mutex> lk(g_rgb_mu);
-        r = g_rgb_set;
-        g_rgb_set = nullptr;
+        drop_rgb.swap(g_rgb_cache);
     }
-    if (r) {
-        r->free_all();
-        delete r;
-    }
+    for (fic_rgb_ctx* c : drop_rgb) fic_rgb_ctx_destroy(c);
     fic_release_comms_();
+    arena_release_all();
 }
 
 int fic_encode_gray_argb(const int32_t* argb, int w, int h, int B, int wK, int n_iso, int device, int32_t* idx_local,

@@ -17,13 +17,16 @@
 //   qrows  : the ints of the .run stream per range {i_local, (int)(a*100), (int)b}  (FC:372-374)
 //   a      = (float) q / 100f  (FC:373), b = (float) q
 //   value  = clamp((int)(a*domain + b))                              (FC:396-402)
-//   SSD    = sum (range - value)^2 as an exact integer.  Java accumulates it in float (FC:407):
-//            identical whenever SSD < 2^24 (all partial sums are then exact floats) -- always the
-//            case for the iteration that ends the loop with avgError < 1 when w*h <= 2^24.
+//   SSD    = sum (range - value)^2 as an exact integer.  Java accumulates it in float, pixel by pixel in
+//            range-block order (FC:385-407): the same number whenever every partial sum is an exact float
+//            (integer carry-in, total < 2^24).  Otherwise -- an iteration that changes a lot, a decode that
+//            does not converge, images above 4096x4096 -- k_decode_step re-accumulates the per-pixel squares
+//            (kept in `sqbuf` in Java's visiting order) sequentially in f32, one add per pixel like FC:407.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_decode_paint(const uint8_t* __restrict__ scaled, uint8_t* __restrict__ image,
                                                       const int32_t* __restrict__ qrows, const int32_t* __restrict__ iso,
-                                                      FicDecodeState* __restrict__ state, int counter, FicGeom g)
+                                                      FicDecodeState* __restrict__ state, uint32_t* __restrict__ sqbuf,
+                                                      int counter, FicGeom g)
 {
     int x = blockIdx.x * 256 + threadIdx.x;
     int y = blockIdx.y;
@@ -53,6 +56,8 @@ __global__ __launch_bounds__(256) void k_decode_paint(const uint8_t* __restrict_
             image[p] = (uint8_t)value;
             sq = (unsigned long long)(d * d);
         }
+        // Java's visiting order: range blocks row-major, pixels row-major inside a block (FC:385-389)
+        sqbuf[(size_t)plane * g.W * g.H + ((size_t)j * g.B + ry) * g.B + rx] = (uint32_t)sq;
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) sq += __shfl_xor(sq, off, 64);
@@ -65,14 +70,32 @@ __global__ __launch_bounds__(256) void k_decode_paint(const uint8_t* __restrict_
     }
 }
 
-// Loop control of FC:413-417, one thread per plane.
-__global__ void k_decode_step(FicDecodeState* __restrict__ state, int counter, int wh, int planes)
+// Loop control of FC:413-417: one wave per plane, lane 0 works.  avgError += ... (FC:407) is a float accumulation:
+// fl(carry + SSD) when that is provably what Java gets, else the sequential sum over sqbuf.
+__global__ __launch_bounds__(64) void k_decode_step(FicDecodeState* __restrict__ state, const uint32_t* __restrict__ sqbuf,
+                                                   int counter, int wh, int planes)
 {
-    int plane = blockIdx.x * blockDim.x + threadIdx.x;
-    if (plane >= planes) return;
+    const int plane = blockIdx.x;
+    if (plane >= planes || threadIdx.x != 0) return;
     FicDecodeState* st = state + plane;
     if (st->done) return;
-    float avg = __fadd_rn(st->avg, (float)st->ssd[counter]);   // avgError += ... (carry-in is 0 after iteration 0)
+    const float carry = st->avg;                               // 0 after iteration 0; the static's old value before it (FC:20)
+    const unsigned long long ssd = st->ssd[counter];
+    float avg;
+    if (carry == truncf(carry) && carry >= 0.0f && (double)carry + (double)ssd < 16777216.0) {
+        avg = __fadd_rn(carry, (float)ssd);                    // every partial sum is an exact float: order is irrelevant
+    } else {
+        const uint4* q = (const uint4*)(sqbuf + (size_t)plane * wh);      // wh is a multiple of 16
+        avg = carry;
+        for (int i = 0; i < wh / 4; i++) {
+            const uint4 v = q[i];
+            avg = __fadd_rn(avg, (float)v.x);
+            avg = __fadd_rn(avg, (float)v.y);
+            avg = __fadd_rn(avg, (float)v.z);
+            avg = __fadd_rn(avg, (float)v.w);
+        }
+        st->seq_sums += 1;
+    }
     avg = __fdiv_rn(avg, (float)wh);                           // FC:413
     st->iters = counter + 1;
     st->avg_out = avg;
@@ -83,20 +106,20 @@ __global__ void k_decode_step(FicDecodeState* __restrict__ state, int counter, i
 
 // host-side launchers
 // loop control of one decoder iteration (shared by the grey and the RGB decoder)
-int fic_launch_decode_step(FicDecodeState* state, int counter, int wh, int planes, hipStream_t s)
+int fic_launch_decode_step(FicDecodeState* state, const uint32_t* sqbuf, int counter, int wh, int planes, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_decode_step, dim3((planes + 63) / 64), dim3(64), 0, s, state, counter, wh, planes);
+    hipLaunchKernelGGL(k_decode_step, dim3(planes), dim3(64), 0, s, state, sqbuf, counter, wh, planes);
     FIC_LAUNCH_CHECK();
     return 0;
 }
 
 // one decoder iteration: scale (FC:382 -> createCodebuch -> scaleImage), paint, loop control
 int fic_launch_decode_iteration(uint8_t* scaled, uint8_t* image, const int32_t* qrows, const int32_t* iso,
-                                FicDecodeState* state, int counter, const FicGeom& g, hipStream_t s)
+                                FicDecodeState* state, uint32_t* sqbuf, int counter, const FicGeom& g, hipStream_t s)
 {
     if (fic_launch_scale(image, scaled, g, s)) return -1;      // FC:382 -> createCodebuch -> scaleImage
     hipLaunchKernelGGL(k_decode_paint, dim3((g.W + 255) / 256, g.H, g.planes), dim3(256), 0, s, scaled, image, qrows, iso,
-                       state, counter, g);
+                       state, sqbuf, counter, g);
     FIC_LAUNCH_CHECK();
-    return fic_launch_decode_step(state, counter, g.W * g.H, g.planes, s);
+    return fic_launch_decode_step(state, sqbuf, counter, g.W * g.H, g.planes, s);
 }

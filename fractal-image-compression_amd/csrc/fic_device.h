@@ -50,7 +50,7 @@ struct FicDecodeState {
     int iters;                    // iterations executed
     int done;                     // loop ended (avgError < 1, FC:414, or counter == 49)
     int bad_index;                // a row pointed outside the pool (Java: ArrayIndexOutOfBounds at FC:394)
-    int pad;
+    int seq_sums;                 // iterations whose sum had to be re-accumulated in Java's order (not exact in float)
 };
 
 // Joint-RGB path (encodeRGB FC:171-219).  Per domain block:

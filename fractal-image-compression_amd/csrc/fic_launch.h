@@ -116,9 +116,10 @@ int fic_launch_sweep_q(const FicBuffers& b, const void* poolQ, const void* dflat
                        void* theta_g, const FicGeom& g, int ct_begin, int ct_end, int ndtiles, int ndtiles_alloc,
                        int nct_alloc, int tiles_per_chunk, int nchunks, hipStream_t s, unsigned long long* stats = nullptr);
 int fic_launch_decode_iteration_rgb(int32_t* scaled, int32_t* image, const int32_t* qrows5, FicDecodeState* state,
-                                    int counter, const FicGeom& g, hipStream_t s);
+                                    uint32_t* sqbuf, int counter, const FicGeom& g, hipStream_t s);
 
 // decoder (FC:356-421)
-int fic_launch_decode_step(FicDecodeState* state, int counter, int wh, int planes, hipStream_t s);
+// sqbuf: u32 [planes][W*H] per-pixel squared changes of the iteration in Java's visiting order (for the sequential f32 sum)
+int fic_launch_decode_step(FicDecodeState* state, const uint32_t* sqbuf, int counter, int wh, int planes, hipStream_t s);
 int fic_launch_decode_iteration(uint8_t* scaled, uint8_t* image, const int32_t* qrows, const int32_t* iso,
-                                FicDecodeState* state, int counter, const FicGeom& g, hipStream_t s);
+                                FicDecodeState* state, uint32_t* sqbuf, int counter, const FicGeom& g, hipStream_t s);

@@ -251,7 +251,8 @@ __global__ __launch_bounds__(256) void k_collage_rgb(const int32_t* __restrict__
 // the squared change of the three channels is summed as an int per pixel before the float add (FC:493).
 __global__ __launch_bounds__(256) void k_decode_paint_rgb(const int32_t* __restrict__ scaled, int32_t* __restrict__ image,
                                                           const int32_t* __restrict__ qrows5,
-                                                          FicDecodeState* __restrict__ st, int counter, FicGeom g)
+                                                          FicDecodeState* __restrict__ st, uint32_t* __restrict__ sqbuf,
+                                                          int counter, FicGeom g)
 {
     int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
     if (st->done) return;
@@ -283,6 +284,7 @@ __global__ __launch_bounds__(256) void k_decode_paint_rgb(const int32_t* __restr
             image[p] = (int32_t)(0xff000000u | ((uint32_t)vR << 16) | ((uint32_t)vG << 8) | (uint32_t)vB);
             sq = (unsigned long long)(dR * dR + dG * dG + dB * dB);
         }
+        sqbuf[((size_t)j * g.B + ry) * g.B + rx] = (uint32_t)sq;     // Java's visiting order (FC:461-466)
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) sq += __shfl_xor(sq, off, 64);
@@ -346,12 +348,12 @@ int fic_launch_rgb_encode(const FicRgbBuffers& b, const FicRgbOutputs& out, int3
 
 // one decodeRGB iteration (FC:458-505): scaleImageRGB of the current image, paint, loop control
 int fic_launch_decode_iteration_rgb(int32_t* scaled, int32_t* image, const int32_t* qrows5, FicDecodeState* state,
-                                    int counter, const FicGeom& g, hipStream_t s)
+                                    uint32_t* sqbuf, int counter, const FicGeom& g, hipStream_t s)
 {
     hipLaunchKernelGGL(k_scale_rgb, dim3((g.Ws + 255) / 256, g.Hs), dim3(256), 0, s, (const int32_t*)image, scaled, g);
     FIC_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_decode_paint_rgb, dim3((g.W + 255) / 256, g.H), dim3(256), 0, s, (const int32_t*)scaled, image,
-                       qrows5, state, counter, g);
+                       qrows5, state, sqbuf, counter, g);
     FIC_LAUNCH_CHECK();
-    return fic_launch_decode_step(state, counter, g.W * g.H, 1, s);
+    return fic_launch_decode_step(state, sqbuf, counter, g.W * g.H, 1, s);
 }

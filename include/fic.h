@@ -148,6 +148,24 @@ FIC_API int fic_ctx_collage_host(fic_ctx* ctx, int32_t* argb_out);
  *   collage_argb  getBestGeneratedCollageRGB (:308-347), w*h ARGB ints; may be NULL */
 FIC_API int fic_encode_rgb_argb(const int32_t* argb, int w, int h, int B, int wK, int device, int32_t* idx_local,
                                 float* a, float* bR, float* bG, float* bB, int32_t* qrows5, int32_t* collage_argb);
+/* Handle API of the same path: the device-resident working set of `planes` colour images of one geometry (a batch of
+ * config-5 style images, or one image encoded again and again); same kernels, same bits as fic_encode_rgb_argb per image.
+ * Input: host ARGB [planes][h][w] (copied) or a device pointer that stays owned by the caller until fic_rgb_ctx_sync.
+ * fic_rgb_ctx_encode is asynchronous on hip_stream; with_collage != 0 also builds getBestGeneratedCollageRGB (:308-347).
+ * Results: [planes][N_r] arrays ([planes][N_r][5] qrows5, [planes][h][w] collage); any pointer may be NULL.
+ * fic_rgb_ctx_decode_host runs decodeRGB (:430-508) from the context's quantised rows: argb_out [planes][h][w],
+ * avg_error_out / iterations_out [planes] (may be NULL). */
+typedef struct fic_rgb_ctx fic_rgb_ctx;
+FIC_API fic_rgb_ctx* fic_rgb_ctx_create(int device, int w, int h, int B, int wK, int planes);
+FIC_API void fic_rgb_ctx_destroy(fic_rgb_ctx* ctx);
+FIC_API int fic_rgb_ctx_set_argb_host(fic_rgb_ctx* ctx, const int32_t* argb);
+FIC_API int fic_rgb_ctx_set_argb_device(fic_rgb_ctx* ctx, const void* dev_argb);
+FIC_API int fic_rgb_ctx_encode(fic_rgb_ctx* ctx, int with_collage, void* hip_stream);
+FIC_API int fic_rgb_ctx_sync(fic_rgb_ctx* ctx);
+FIC_API int fic_rgb_ctx_get_results_host(fic_rgb_ctx* ctx, int32_t* idx_local, float* a, float* bR, float* bG, float* bB,
+                                         int32_t* qrows5, int32_t* collage_argb);
+FIC_API int fic_rgb_ctx_decode_host(fic_rgb_ctx* ctx, int32_t* argb_out, float* avg_error_out, int* iterations_out);
+
 /* writeData, RGB branch (FractalCompression.java:230-238, 248-257): header {1,w,h,B,wK} + 5 ints per row. */
 FIC_API int64_t fic_write_run_rgb(const int32_t* qrows5, int n_ranges, int w, int h, int B, int wK, uint8_t* out,
                                   int64_t capacity);
@@ -162,8 +180,9 @@ FIC_API int64_t fic_write_run_rgb(const int32_t* qrows5, int n_ranges, int w, in
  *                   :20,:407); out: its value after the call = the GUI's "MSE" label
  *                   (RLEAppController.java:180).  May be NULL (treated as 0).
  *   iterations      iterations executed; may be NULL.
- * The per-iteration sum is an exact integer on the device; it equals Java's float accumulation
- * whenever it is below 2^24, which holds for the iteration that ends a converging decode. */
+ * avgError is Java's float accumulation (:407), one add per pixel in range-block order: taken from the exact integer sum
+ * when every partial sum is an exact float, re-accumulated sequentially in that order otherwise (large or
+ * non-converging decodes), so the returned value and the "< 1" decision (:413-415) match for any size. */
 FIC_API int fic_decode_gray_run(const uint8_t* run, int64_t len, int device, uint8_t* gray_out, int64_t capacity,
                                 int* w, int* h, float* avg_error_io, int* iterations);
 /* decodeRGB (FractalCompression.java:430-508) on a complete colour .run stream (isRGB != 0):
@@ -205,6 +224,9 @@ FIC_API int fic_ctx_info(fic_ctx* ctx, int* out10);
 /* Test hook: out[i] = sqrt((double)(first + i)) computed on the device exactly as the pool
  * kernel does for Domainblock.variance (FractalCompression.java:677,680 Math.sqrt). */
 FIC_API int fic_debug_sqrt_f64(int device, uint32_t first, uint32_t count, double* out);
+/* Test hook: fic_decode_gray_run that also reports in seq_sums how many iterations took the sequential float sum. */
+FIC_API int fic_debug_decode_gray_run(const uint8_t* run, int64_t len, int device, uint8_t* gray_out, int64_t capacity,
+                                      float* avg_error_io, int* iterations, int* seq_sums);
 /* Test hook: loads RCCL, creates one communicator per device 0..n-1 and (n >= 2) runs the codebook gather's grouped
  * send/recv pattern on dummy records, checking what arrives on device 0. */
 FIC_API int fic_debug_rccl_selftest(int n);

@@ -135,3 +135,39 @@ def test_config5_per_channel_encode(lena_colored, oracle):
             assert (got["idx_local"][i, c] == ref["info"][:, 0].astype(np.int32)).all()
             assert (got["iso"][i, c] == ref["iso"]).all()
             assert same_f32(got["a"][i, c], ref["info"][:, 1]) and same_f32(got["b"][i, c], ref["info"][:, 2])
+
+
+@pytest.mark.parametrize("B,wK", [(8, 2), (8, None), (4, 5)])
+def test_rgb_context_batched_planes_equal_one_shot(oracle, lena_colored, B, wK):
+    """fic_rgb_ctx_*: a batch of colour images in one device-resident context (config-5 style) gives, per image, the bits
+    of the one-shot entry; the context decodes its own codebook (decodeRGB) to what the oracle's decoder produces."""
+    import torch
+    size = 128 if wK is None else 256
+    imgs = [lena_colored[:size, :size], _rgb_synth(size, size, 41), _rgb_synth(size, size, 52, flat=True)]
+    argbs = [oracle.rgb_to_argb(np.ascontiguousarray(x)) for x in imgs]
+    Dw = fic_amd.geometry(size, size, B)[2]
+    wk = Dw if wK is None else wK
+    with fic_amd.capi.RgbEncoder(size, size, B, wk, planes=3) as enc:
+        enc.set_argb(np.stack(argbs))
+        enc.encode(with_collage=True)
+        r = enc.results()
+        dec, avg, it = enc.decode()
+        # the same batch from a device-resident input, without the collage
+        t = torch.from_numpy(np.stack(argbs)).cuda()
+        enc.set_argb(t)
+        enc.encode(with_collage=False, stream=torch.cuda.current_stream())
+        enc.sync()
+        r2 = enc.results()
+    for p, argb in enumerate(argbs):
+        one = fic_amd.encode_rgb(argb, size, size, B, wk, want_collage=True)
+        for k in ("idx_local", "qrows"):
+            assert (r[k][p] == one[k]).all() and (r2[k][p] == one[k]).all()
+        for k in ("a", "bR", "bG", "bB"):
+            assert same_f32(r[k][p], one[k]) and same_f32(r2[k][p], one[k])
+        assert (r["collage"][p] == one["collage"]).all()
+        run = fic_amd.write_run_rgb(r["qrows"][p], size, size, B, wk)
+        want, wavg, wit = oracle.decode_rgb(run)
+        u = dec[p].view(np.uint32)
+        got = np.stack([(u >> 16) & 0xFF, (u >> 8) & 0xFF, u & 0xFF], -1).reshape(size, size, 3)
+        assert (got == want).all() and it[p] == wit and avg[p].view(np.uint32) == np.float32(wavg).view(np.uint32)
+    fic_amd.capi.release_cache()
