@@ -85,8 +85,8 @@ def kernel_name(kind, B, n_iso):
         return ("k_sweep_bf16" if bf16 else "k_sweep_mfma") + ("" if n_iso == 8 else ("_1" if bf16 else "1")), ("bf16" if bf16 else "i8")
     if kind == 4:
         return "k_sweep_mfma" + ("" if n_iso == 8 else "1"), "i8"
-    if kind == 6:
-        return ("k_sweep_q8" if n_iso == 8 else "k_sweep_q1"), "f16"
+    if kind == 6:     # k_sweep_q<NK, MODE>: NK = n/16 MFMA steps, MODE 0 = 1 isometry, 1 = 8 isometries (B = 4), 2 = 8 isometries folded
+        return f"k_sweep_q<{B * B // 16}, {0 if n_iso == 1 else (1 if B == 4 else 2)}>", "f16"
     return SWEEP_KINDS.get(kind, ("k_sweep_fast", None))[0], None
 
 
@@ -415,12 +415,19 @@ def main():
             # matrix-core sweeps: algorithmic work = 2n flop per pair evaluation (n MACs per pair)
             peak = MFMA_PEAK_TFLOPS[operand]
             ops = pair_evals * 2.0 * n
+            # k_sweep_q's folded mode (8 isometries at B = 8 / 16) gets the 8 inner products of a (range, domain) pair from
+            # 4 even + 4 odd rows of K = n/2: half the matrix instructions of the algorithmic count
+            executed = ops * (0.5 if (kind == 6 and n_iso == 8 and B >= 8) else 1.0)
             roofline = {"bound": "mfma", "achieved": ops / (avg_ms * 1e-3) / 1e12, "peak": peak,
                         "unit": "TFLOP/s" if operand != "i8" else "TOP/s", "frac": ops / (avg_ms * 1e-3) / 1e12 / peak,
                         "traffic": traffic, "traffic_note": traffic_note, "kernel": kname, "operands": operand,
                         "avg_launch_ms": avg_ms, "launches": sweep_n, "algorithmic_flop_per_launch": ops,
-                        "note": "algorithmic flop = range blocks x N_d x n_iso x 2n per launch; duration from HIP events on the "
-                                "sweep's stream inside the timed region"}
+                        "executed_flop_per_launch": executed, "matrix_pipe_frac": executed / (avg_ms * 1e-3) / 1e12 / peak,
+                        "note": "achieved / frac: ALGORITHMIC flop = range blocks x N_d x n_iso x 2n per launch (SURVEY 8d: n MACs per "
+                                "pair evaluation) over the HIP-event duration of the launch on the sweep's stream, inside the timed "
+                                "region.  executed_flop / matrix_pipe_frac: what the matrix cores really issue -- the folded 8-isometry "
+                                "form needs half the MACs (DESIGN.md 4.5), so frac can exceed matrix_pipe_frac by 2x; matrix_pipe_frac "
+                                "is the utilisation against the 2.4 GHz peak (the chip holds ~1.9 GHz under this load: profiles/)"}
         else:
             # VALU instructions per pair evaluation of the sweep kernel (static count from the ISA):
             # k_sweep_fast: n/4 v_dot4 per pair evaluation, plus per (range, domain): 1 iso -> 5; 8 iso -> 15, shared by 8

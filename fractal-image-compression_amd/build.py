@@ -38,7 +38,8 @@ def needs_build():
 def build(force=False, verbose=False):
     if not force and not needs_build():
         return SO
-    cmd = [_hipcc()] + FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", SO]
+    # FIC_HIPCC_FLAGS: extra compiler flags for experiments (e.g. -DFIC_Q_SCHED=1); empty in normal builds
+    cmd = [_hipcc()] + FLAGS + os.environ.get("FIC_HIPCC_FLAGS", "").split() + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", SO]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd, cwd=CSRC)

@@ -102,6 +102,7 @@ def lib():
         "fic_ctx_info": (C.c_int, [vp, ip]),
         "fic_ctx_sweep_stats": (C.c_int, [vp, C.POINTER(C.c_uint64), C.c_int]),
         "fic_debug_rccl_selftest": (C.c_int, [C.c_int]),
+        "fic_debug_float_sum": (C.c_int, [C.c_int, C.c_float, C.POINTER(C.c_uint32), C.c_int, f32p]),
         "fic_debug_decode_gray_run": (C.c_int, [u8p, C.c_int64, C.c_int, u8p, C.c_int64, f32p, ip, ip]),
         "fic_debug_sqrt_f64": (C.c_int, [C.c_int, C.c_uint32, C.c_uint32, C.POINTER(C.c_double)]),
         "fic_ctx_debug_pool_host": (C.c_int, [vp, u8p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), u8p]),

@@ -443,9 +443,10 @@ int q_sweep(fic_ctx* c, int tile0, int tile1, hipStream_t s, int* nchunks_out)
     int nchunks = c->opt_chunks;
     if (nchunks <= 0) {
         // a chunk's start-up is about one domain tile of extra work per range (fic_q.hip), so chunks only need to be
-        // long enough to hide that (>= 16 tiles) and numerous enough to fill the chip (~8 workgroups per CU)
+        // long enough to hide that (>= 16 tiles) and numerous enough to fill the chip: the kernels run two workgroups per
+        // CU (VGPR-bound), i.e. 512 at a time -- two rounds of them balance the tail
         const long long base_wg = (long long)((ct_end - ct_begin + q.CT - 1) / q.CT) * g.planes;
-        long long want = (2048 + base_wg - 1) / base_wg;
+        long long want = (1024 + base_wg - 1) / base_wg;
         long long cap = q.ndtiles / 16;
         if (cap < 1) cap = 1;
         nchunks = (int)(want < cap ? want : cap);
@@ -1027,6 +1028,29 @@ int fic_decode_gray_run(const uint8_t* run, int64_t len, int device, uint8_t* gr
                         int* h_out, float* avg_error_io, int* iterations)
 {
     return decode_gray_run_impl(run, len, device, gray_out, capacity, w_out, h_out, avg_error_io, iterations, nullptr);
+}
+
+// Test hook: the decoder's reproduction of Java's `avgError += (float) v[i]` loop (FC:407) on arbitrary values.
+int fic_debug_float_sum(int device, float carry, const uint32_t* vals, int count, float* out)
+{
+    if (!vals || !out || count < 0) return fail(FIC_E_ARGUMENT, "fic_debug_float_sum: bad argument");
+    int ndev = fic_device_count();
+    if (ndev <= 0 || device < 0 || device >= ndev) return fail(FIC_E_NO_DEVICE, "no HIP device %d", device);
+    HIP_TRY(hipSetDevice(device));
+    uint32_t* d = nullptr;
+    float* r = nullptr;
+    HIP_TRY(hipMalloc((void**)&d, (size_t)(count + 4) * 4));
+    hipError_t e = hipMalloc((void**)&r, 4);
+    if (e == hipSuccess) e = hipMemcpy(d, vals, (size_t)count * 4, hipMemcpyHostToDevice);
+    int rc = e == hipSuccess ? FIC_OK : fail(FIC_E_HIP, "fic_debug_float_sum: %s", hipGetErrorString(e));
+    if (rc == FIC_OK && fic_launch_float_sum_probe(carry, d, count, r, nullptr)) rc = fail(FIC_E_HIP, "k_float_sum_probe launch failed");
+    if (rc == FIC_OK) {
+        e = hipMemcpy(out, r, 4, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = fail(FIC_E_HIP, "fic_debug_float_sum: %s", hipGetErrorString(e));
+    }
+    (void)hipFree(d);
+    if (r) (void)hipFree(r);
+    return rc;
 }
 
 // Test hook: fic_decode_gray_run that also reports how many iterations needed the sequential (Java-order) float sum.

@@ -119,6 +119,7 @@ int fic_launch_decode_iteration_rgb(int32_t* scaled, int32_t* image, const int32
                                     uint32_t* sqbuf, int counter, const FicGeom& g, hipStream_t s);
 
 // decoder (FC:356-421)
+int fic_launch_float_sum_probe(float carry, const uint32_t* vals, int count, float* out, hipStream_t s);
 // sqbuf: u32 [planes][W*H] per-pixel squared changes of the iteration in Java's visiting order (for the sequential f32 sum)
 int fic_launch_decode_step(FicDecodeState* state, const uint32_t* sqbuf, int counter, int wh, int planes, hipStream_t s);
 int fic_launch_decode_iteration(uint8_t* scaled, uint8_t* image, const int32_t* qrows, const int32_t* iso,

@@ -62,8 +62,7 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 #define FIC_Q_QFLUSH 256                   // evaluate the queue before a tile's pushes once it holds this many
 
 __host__ __device__ constexpr int fic_q_ctw(int NK) { return NK <= 4 ? 4 : 2; }   // column tiles (x32 range copies) per wave
-// prefetch distance of the domain fragments in tiles (= VGPR buffers - 1 = the sweep loop's unroll factor - 1)
-__host__ __device__ constexpr int fic_q_pf(int NK, int MODE) { return (NK == 4 && MODE != 2) ? 2 : 1; }
+#define FIC_Q_UNROLL 2                     // domain tiles per iteration of the sweep loop (two fragment buffers swap roles)
 
 // two floats -> packed f16 pair (round to nearest even), element 0 in the low half
 __device__ __forceinline__ int f16_pair(float lo, float hi)
@@ -409,7 +408,6 @@ __global__ __launch_bounds__(256) void k_sweep_q(QArgs A)
     constexpr int CSHIFT = QMode<MODE>::CSHIFT;
     constexpr bool FOLD = MODE == 2;
     constexpr int NKA = FOLD ? NK / 2 : NK;                  // MFMA steps per accumulator
-    constexpr int PF = fic_q_pf(NK, MODE);                   // prefetch distance in domain tiles = buffers - 1
     __shared__ uint32_t sQ[4][FIC_Q_QCAP];             // per wave: domain block | column-in-wave << 24
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -530,30 +528,30 @@ __global__ __launch_bounds__(256) void k_sweep_q(QArgs A)
         }
     };
 
-    // Fragment buffers in rotation.  PF = 2: a step computes on `ac`, finishes with the first tile of `an` (loaded during the
-    // previous step) and starts the loads of `ld`, two domain tiles ahead (~1.75 steps to land); PF = 1 (where registers
-    // are short): two buffers, the next tile's loads start at the top of the step.
-    v4i a0[NK], a1[NK], a2[PF == 2 ? NK : 1];
+    // Two fragment buffers.  A step computes on `ac` (domain tile dt) and finishes with the first tile of `an` (tile dt + 1);
+    // as soon as the last MFMAs that read `ac` have been issued (column tile CTW-1), `ac` is reloaded with tile dt + 2, which
+    // is first needed at the end of the NEXT step: every load has CTW + 1 tile epilogues (a step and a quarter) to land.
+    v4i a0[NK], a1[NK];
 #pragma unroll
     for (int m = 0; m < NK; m++) a0[m] = pa[((size_t)dt0 * NK + m) * 64];
-    if constexpr (PF == 2) {
 #pragma unroll
-        for (int m = 0; m < NK; m++) a1[m] = pa[((size_t)(dt0 + 1) * NK + m) * 64];
-    }
+    for (int m = 0; m < NK; m++) a1[m] = pa[((size_t)(dt0 + 1) * NK + m) * 64];
     v16f acc, acc2 = zero;
     tile_mfma(a0, rb[0], acc, acc2);
 
-    // one domain tile; `ld` receives tile dt + PF (the fragment store has spare zero tiles behind the pool)
-    auto step = [&](int dt, const v4i (&ac)[NK], const v4i (&an)[NK], v4i (&ld)[NK]) __attribute__((always_inline)) {
+    // one domain tile (the fragment store has spare zero tiles behind the pool for the loop's overrun and the prefetch)
+    auto step = [&](int dt, v4i (&ac)[NK], const v4i (&an)[NK]) __attribute__((always_inline)) {
         const bool first = dt == dt0;
-#pragma unroll
-        for (int m = 0; m < NK; m++) ld[m] = pa[((size_t)(dt + PF) * NK + m) * 64];
 #pragma unroll
         for (int ci = 0; ci < CTW; ci++) {
             // the next tile's MFMAs: column tile ci+1 of this domain tile, or column tile 0 of the next domain tile
             v16f nacc, nacc2 = zero;
             if (ci + 1 < CTW) tile_mfma(ac, rb[ci + 1], nacc, nacc2);
             else tile_mfma(an, rb[0], nacc, nacc2);
+            if (ci == CTW - 2) {
+#pragma unroll
+                for (int m = 0; m < NK; m++) ac[m] = pa[((size_t)(dt + 2) * NK + m) * 64];
+            }
             const float mx = FOLD ? max16_sum(acc, acc2) : max16_abs(acc);
             const bool hit = mx > tau[ci];
             if constexpr (NK == 4 && !FOLD) {
@@ -565,6 +563,10 @@ __global__ __launch_bounds__(256) void k_sweep_q(QArgs A)
                 __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
                 __builtin_amdgcn_sched_group_barrier(0x2, 3, 0);
             } else if constexpr (NK == 4 && FOLD) {
+#ifndef FIC_Q_SCHED
+#define FIC_Q_SCHED 3
+#endif
+#if FIC_Q_SCHED == 0
                 // 4 MFMAs (two 2-step accumulators), 16 adds + 8 max + compare: M M v*8 M v*8 M v*9
                 __builtin_amdgcn_sched_group_barrier(0x8, 2, 0);
                 __builtin_amdgcn_sched_group_barrier(0x2, 8, 0);
@@ -572,6 +574,19 @@ __global__ __launch_bounds__(256) void k_sweep_q(QArgs A)
                 __builtin_amdgcn_sched_group_barrier(0x2, 8, 0);
                 __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
                 __builtin_amdgcn_sched_group_barrier(0x2, 9, 0);
+#elif FIC_Q_SCHED == 2
+                __builtin_amdgcn_sched_group_barrier(0x8, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x2, 25, 0);
+#elif FIC_Q_SCHED == 3
+                __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x2, 6, 0);
+                __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x2, 6, 0);
+                __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x2, 6, 0);
+                __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x2, 7, 0);
+#endif
             }
             // a chunk's first tile always takes the slow path: theta is seeded there and candidate 0 is queued
             if (__builtin_expect((__builtin_amdgcn_ballot_w64(hit) != 0) | first, 0)) slow_tile(acc, acc2, mx, ci, dt, first);
@@ -579,17 +594,9 @@ __global__ __launch_bounds__(256) void k_sweep_q(QArgs A)
             if constexpr (FOLD) acc2 = nacc2;
         }
     };
-    if constexpr (PF == 2) {
-        for (int dt = dt0; dt < dt1; dt += 3) {
-            step(dt, a0, a1, a2);
-            step(dt + 1, a1, a2, a0);
-            step(dt + 2, a2, a0, a1);
-        }
-    } else {
-        for (int dt = dt0; dt < dt1; dt += 2) {
-            step(dt, a0, a1, a1);
-            step(dt + 1, a1, a0, a0);
-        }
+    for (int dt = dt0; dt < dt1; dt += 2) {
+        step(dt, a0, a1);
+        step(dt + 1, a1, a0);
     }
     flush();
     if (A.stats && lane == 0) {
@@ -607,7 +614,7 @@ int fic_q_ct(int B) { return 4 * fic_q_ctw(B * B / 16); }       // column tiles 
 // 0: 1 isometry; 1: 8 isometries, one column per copy; 2: 8 isometries folded into 4 columns per range block
 int fic_q_mode(int B, int n_iso) { return n_iso == 1 ? 0 : (B == 4 ? 1 : 2); }
 int fic_q_cols_per_range(int B, int n_iso) { const int m = fic_q_mode(B, n_iso); return m == 0 ? 1 : (m == 1 ? 8 : 4); }
-int fic_q_unroll(int B, int n_iso) { return fic_q_pf(B * B / 16, fic_q_mode(B, n_iso)) + 1; }
+int fic_q_unroll(int B, int n_iso) { (void)B; (void)n_iso; return FIC_Q_UNROLL; }
 
 int fic_launch_q_prep(const FicBuffers& b, void* poolQ, void* dflat, void* rngQ, void* rngE, void* theta_g,
                       const FicGeom& g, int ndtiles_alloc, int nct_alloc, int grp0, int ngrp, hipStream_t s)

@@ -83,3 +83,40 @@ def test_non_converging_rgb_codebook(oracle):
     assert it == want_it == 50
     assert (got == want).all()
     assert np.float32(avg).view(np.uint32) == np.float32(want_avg).view(np.uint32)
+
+
+def _seq_sum(carry, vals):
+    s = np.float32(carry)
+    for v in vals.astype(np.float32):
+        s = np.float32(s + v)
+    return s
+
+
+@pytest.mark.parametrize("case", ["squares", "ties", "powers", "rgb_max", "small", "fractional", "crossing"])
+def test_float_accumulation_scan_equals_the_sequential_loop(case):
+    """java_float_sum (parallel scan over parity-dependent rounding maps) against `s = fl(s + v)` in order, on inputs
+    chosen to hit round-to-even ties, binade crossings inside a block, and a fractional carry-in."""
+    rng = np.random.default_rng(11)
+    n = 300000
+    carry = 0.0
+    if case == "squares":
+        vals = rng.integers(0, 256, n) ** 2
+    elif case == "ties":            # multiples of 2^j: exactly half an ulp once the sum is in the right binade
+        vals = (rng.integers(0, 64, n) << rng.integers(0, 12, n)).astype(np.int64)
+    elif case == "powers":
+        vals = 1 << rng.integers(0, 18, n)
+    elif case == "rgb_max":
+        vals = np.full(n, 3 * 255 * 255)
+    elif case == "small":
+        vals = rng.integers(0, 3, 40000)
+    elif case == "fractional":
+        carry = 0.36376953
+        vals = rng.integers(0, 3000, n)
+    else:                           # sums hovering around 2^24, 2^25, ...: crossings in the middle of 16384-value blocks
+        vals = np.concatenate([np.full(16000, 1000), rng.integers(0, 5, 50000), np.full(20000, 1700), rng.integers(0, 9, 50000)])
+    vals = np.ascontiguousarray(vals, np.uint32)
+    if case in ("small", "powers"):
+        vals = vals[:-3]            # a length that is not a multiple of 4
+    out = C.c_float()
+    capi.check(capi.lib().fic_debug_float_sum(0, C.c_float(carry), capi.ptr(vals, C.c_uint32), vals.size, C.byref(out)))
+    assert np.float32(out.value).view(np.uint32) == _seq_sum(carry, vals).view(np.uint32)

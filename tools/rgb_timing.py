@@ -7,6 +7,9 @@ import sys
 import time
 
 import numpy as np
+import torch
+
+torch.cuda.init()          # torch's bundled HIP runtime must come up before libfic_hip.so's (capi._torch_first)
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import fic_amd  # noqa: E402
@@ -29,3 +32,30 @@ for W in (256, 512, 1024):
             out[f"{W}x{W}_B{B}_wK{wK}{'_full' if wK == Dw else ''}"] = {"ms_per_call": dt * 1e3, "matches_per_s": nr / dt,
                                                                         "pair_evals_per_s": nr * wK * wK / dt}
 print(json.dumps(out, indent=1))
+
+# batched, device-resident contexts (fic_rgb_ctx_*): a batch of colour images, input already in HBM
+ctx = {}
+for W, planes, wK in ((256, 16, 2), (256, 16, None), (512, 8, 16), (512, 8, None), (1024, 8, None)):
+    B = 8
+    Dw = fic_amd.geometry(W, W, B)[2]
+    wk = Dw if wK is None else wK
+    imgs = []
+    for p in range(planes):
+        r, g, b = (fic_amd.synth.image_u(W, W, 0xC0200 + 7 * p + c).astype(np.int64) for c in range(3))
+        imgs.append(((np.int64(255) << 24) | (r << 16) | (g << 8) | b).astype(np.uint32).view(np.int32).reshape(-1))
+    t = torch.from_numpy(np.stack(imgs)).cuda()
+    with capi.RgbEncoder(W, W, B, wk, planes) as enc:
+        enc.set_argb(t)
+        s = torch.cuda.current_stream()
+        enc.encode(False, s)
+        enc.sync()
+        reps = 3 if wK is None and W >= 1024 else 10
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            enc.encode(False, s)
+        enc.sync()
+        dt = (time.perf_counter() - t0) / reps
+    nr = (W // B) ** 2 * planes
+    ctx[f"{planes}x{W}x{W}_B{B}_wK{wk}{'_full' if wK is None else ''}"] = {"ms_per_batch": dt * 1e3, "ms_per_image": dt * 1e3 / planes,
+                                                                             "matches_per_s": nr / dt}
+print(json.dumps({"rgb_contexts_device_resident": ctx}, indent=1))
