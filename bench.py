@@ -340,7 +340,8 @@ def main():
             if gathered[k] is not None:
                 compute.wait_event(gathered[k])           # the gather that last read stage[k] has finished
             core.encode(begin, count, compute)
-            stage[k] = records[:, begin:begin + count].contiguous() if stage[k] is None else stage[k].copy_(records[:, begin:begin + count])
+            # always a copy: the next encode rewrites `records` while the gather of this step is still reading
+            stage[k] = records[:, begin:begin + count].clone() if stage[k] is None else stage[k].copy_(records[:, begin:begin + count])
             staged[k] = torch.cuda.Event()
             staged[k].record(compute)
         cur = torch.cuda.current_stream()
