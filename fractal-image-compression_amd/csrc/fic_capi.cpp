@@ -538,7 +538,6 @@ fic_ctx* fic_ctx_create(int device, int w, int h, int B, int wK, int n_iso, int 
     A(dev_alloc(&c->b.pool_st, P * g.Nd_pad));
     A(dev_alloc(&c->b.pool_var, P * g.Nd_pad));
     A(dev_alloc(&c->b.pool_s64, P * g.Nd_pad));
-    A(dev_alloc(&c->b.rng_pix, P * g.Nr_pad * g.n_iso * g.DW));
     A(dev_alloc(&c->b.rng_st, P * g.Nr_pad));
     A(dev_alloc(&c->b.key, P * g.Nr_pad));
     A(dev_alloc(&c->o.idx_local, P * g.Nr));
@@ -662,6 +661,12 @@ int fic_ctx_encode(fic_ctx* c, int range_begin, int range_count, void* hip_strea
     } else {
         if (fic_launch_pool(c->b.scaled, c->b.pool_pix, c->b.pool_st, c->b.pool_var, c->b.pool_s64, g, s))
             return fail(FIC_E_HIP, "k_pool launch failed");
+        // the lane-transposed store of range blocks + isometry copies: only these sweeps read it (134 MB at 4096x4096 with
+        // 8 isometries), so it is allocated on their first use, not with the context
+        if (kind != 5 && !c->b.rng_pix) {
+            int rca = dev_alloc(&c->b.rng_pix, (size_t)g.planes * g.Nr_pad * g.n_iso * g.DW);
+            if (rca) return rca;
+        }
         // k_sweep_d4 reads its own slot store and the finaliser reads the image: no isometry copies to build then
         if (fic_launch_range(c->b.gray, c->b.rng_pix, c->b.rng_st, g, s, kind == 5 ? 0 : 1)) return fail(FIC_E_HIP, "k_range launch failed");
         // one 2-D fill: rows = planes (pitch Nr_pad keys), width = the tile span of this shard

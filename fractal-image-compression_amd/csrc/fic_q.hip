@@ -492,21 +492,33 @@ __global__ __launch_bounds__(256) void k_sweep_q(QArgs A)
         }
         // candidate 0 = (block 0, copy 0): always evaluated (MODE 2: with its partner, copy 2)
         const bool cand0 = first && dt == 0 && half == 0 && ok && (jcol & ((1 << CSHIFT) - 1)) == 0;
-        float mp = -1.0f;                                    // largest flagged test value on this lane
+        // Per-lane mask of the elements above theta, built without scalar branches: bit e = sign(theta - value_e), shifted in by
+        // v_alignbit.  (Strict '>': value == theta gives +0.  theta = "none" (-1) flags everything, zeros included.)
+        uint32_t hm = 0;
 #pragma unroll
-        for (int e = 0; e < 16; e++) {
-            const float ve = val(acc, acc2, e);
-            const bool pe = (ok && ve > tau[ci]) || (e == 0 && cand0);
-            const unsigned long long be = __builtin_amdgcn_ballot_w64(pe);
-            if (be == 0) continue;
-            const int idx = qn + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(be >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)be, 0u));
-            if (pe) {
-                myq[idx] = ent0 + (uint32_t)((e & 3) + 8 * (e >> 2));
-                mp = fmaxf(mp, ve);
-            }
-            qn += __builtin_popcountll(be);
-            st_pairs += (unsigned)__builtin_popcountll(be);
+        for (int e = 15; e >= 0; e--)
+            hm = __builtin_amdgcn_alignbit(hm, __float_as_uint(__fsub_rn(tau[ci], val(acc, acc2, e))), 31);
+        if (!ok) hm = 0;
+        if (cand0) hm |= 1u;
+        const int cnt = __builtin_popcount(hm);
+        // queue offsets: exclusive prefix over the (few) lanes that have something, walked in SGPRs
+        unsigned long long lanes = __builtin_amdgcn_ballot_w64(cnt != 0);
+        int mybase = 0, total = 0;
+        while (lanes) {
+            const int L = __builtin_ctzll(lanes);
+            lanes &= lanes - 1;
+            const int cL = __builtin_amdgcn_readlane(cnt, L);
+            if (lane == L) mybase = total;
+            total += cL;
         }
+        for (uint32_t h = hm, w = (uint32_t)(qn + mybase); h; h &= h - 1, w++) {
+            const int e = __builtin_ctz(h);
+            myq[w] = ent0 + (uint32_t)((e & 3) + 8 * (e >> 2));
+        }
+        qn += total;
+        st_pairs += (unsigned)total;
+        // a lane with flagged elements has its largest element among them: that is mx
+        const float mp = cnt != 0 ? mx : -1.0f;
         // (2): level of the best flagged entry, shared by the lanes of the range
         const float lo2 = q_share_max<MODE>((mayraise && mp >= 0.0f) ? __fsub_rn(mp, E[ci]) : -1.0f);
         if (mayraise && lo2 >= 0.0f) {
