@@ -10,8 +10,8 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 SO = os.path.join(HERE, "libfic_hip.so")
-SOURCES = ["fic_prep.hip", "fic_sweep.hip", "fic_mfma.hip", "fic_bf16.hip", "fic_q.hip", "fic_d4.hip", "fic_decode.hip", "fic_rgb.hip", "fic_capi.cpp"]
-HEADERS = ["fic_device.h", "fic_launch.h", "fic_devfn.h", "fic_d4_tables.h", os.path.join("..", "..", "include", "fic.h")]
+SOURCES = ["fic_prep.hip", "fic_sweep.hip", "fic_mfma.hip", "fic_bf16.hip", "fic_q.hip", "fic_d4.hip", "fic_decode.hip", "fic_rgb.hip", "fic_capi.cpp", "fic_capi_decode.cpp", "fic_capi_rgb.cpp", "fic_capi_multi.cpp"]
+HEADERS = ["fic_device.h", "fic_launch.h", "fic_devfn.h", "fic_internal.h", "fic_d4_tables.h", os.path.join("..", "..", "include", "fic.h")]
 # -ffp-contract=off: the Java reference never fuses a*b+c (FractalCompression.java:641,683);
 # hipcc's device default is "fast".  No fast-math: f32 divide/sqrt stay correctly rounded.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",

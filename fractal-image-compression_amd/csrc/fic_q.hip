@@ -61,7 +61,10 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 #define FIC_Q_QCAP 1280                    // queue entries per wave: one tile can flag at most 1024 pairs
 #define FIC_Q_QFLUSH 256                   // evaluate the queue before a tile's pushes once it holds this many
 
-__host__ __device__ constexpr int fic_q_ctw(int NK) { return NK <= 4 ? 4 : 2; }   // column tiles (x32 range copies) per wave
+#ifndef FIC_Q_CTW_B8
+#define FIC_Q_CTW_B8 4
+#endif
+__host__ __device__ constexpr int fic_q_ctw(int NK) { return NK == 4 ? FIC_Q_CTW_B8 : (NK < 4 ? 4 : 2); }   // column tiles (x32 range copies) per wave
 #define FIC_Q_UNROLL 2                     // domain tiles per iteration of the sweep loop (two fragment buffers swap roles)
 
 // two floats -> packed f16 pair (round to nearest even), element 0 in the low half
