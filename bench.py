@@ -57,6 +57,7 @@ WORKLOADS = {
 
 HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "i8": 5000.0}   # dense peaks, MI355X_MICROARCH.md "Matrix cores"
+PEAK_CLOCK_GHZ = 2.4                     # the clock those peaks are quoted at
 # Measured on MI355X (profiles/r01_valu_issue_rate_microbench.txt): v_dot4_u32_u8 -- like v_mad_i32_i24,
 # v_cvt_*, v_cmp_* and any VALU op with an SGPR source -- issues one wave64 instruction per 4 cycles
 # per SIMD (only plain v_fma_f32 / v_add_u32 reach 2 cycles).  Peak for the VALU sweeps' instruction mix:
@@ -223,6 +224,8 @@ def parse_args(argv=None):
                     help="0 = library default (matrix-core sweep for full search); 2 / 5 = VALU-only sweeps (k_sweep_fast / "
                          "k_sweep_d4, north_star's literal design); 3 / 4 = matrix-core sweeps with exact covariances "
                          "(bf16 / i8 operands); 6 = matrix-core sweep with the normalised f16 prune GEMM")
+    ap.add_argument("--pipeline", type=int, default=1, choices=[1, 2],
+                    help="contexts/streams that take the steps alternately (2: prep of step k+1 overlaps the tail of sweep k)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-alt", action="store_true", help="skip the extra timings (valu_only, single_image)")
     ap.add_argument("--cpu-budget", type=float, default=12.0)
@@ -307,41 +310,58 @@ def main():
         imgs = np.stack([make_image(seed + 3 * p) for p in range(planes)])
     dev_in = torch.from_numpy(imgs).cuda()
 
-    if scaling == "strong":
-        enc = fic_amd.ShardedEncoder(W, H, B, None, n_iso, planes, local_rank)
-        core = enc.enc
-        spans = enc.spans
-    else:
-        core = fic_amd.Encoder(W, H, B, None, n_iso, planes, local_rank)
-        spans = [(0, core.n_ranges)] * world
+    # `--pipeline 2`: two contexts on two streams take the steps alternately, so the pool build / range prep of step k+1 and
+    # the ragged tail of sweep k overlap on the chip (every step still does all of its work inside the timed region).  The
+    # headline run keeps depth 1: with two sweeps sharing the chip a launch's HIP-event duration is no longer the time the
+    # kernel needs, and `roofline` must come from the same timed region as `value`.  N = 1 reports depth 2 beside it.
+    depth = max(1, min(2, args.pipeline))
+    want_pipelined_leg = world == 1 and not args.no_alt and depth == 1
+    cores = []
+    for _ in range(2 if want_pipelined_leg else depth):
+        if scaling == "strong":
+            enc = fic_amd.ShardedEncoder(W, H, B, None, n_iso, planes, local_rank)
+            c_, spans = enc.enc, enc.spans
+        else:
+            c_ = fic_amd.Encoder(W, H, B, None, n_iso, planes, local_rank)
+            spans = [(0, c_.n_ranges)] * world
+        c_.set_gray(dev_in)
+        c_.set_option("time_sweep", 1)
+        if args.chunks:
+            c_.set_option("chunks", args.chunks)
+        if args.sweep:
+            c_.set_option("sweep", args.sweep)
+        cores.append(c_)
+    core = cores[0]
     begin, count = spans[rank]
-    core.set_gray(dev_in)
-    core.set_option("time_sweep", 1)
-    if args.chunks:
-        core.set_option("chunks", args.chunks)
-    if args.sweep:
-        core.set_option("sweep", args.sweep)
-    # The sweep runs on a compute stream of its own; the codebook gather of step k runs on torch's current stream
-    # (where the nccl backend orders its collectives) and overlaps with the sweep of step k+1.
-    compute = torch.cuda.Stream()
-    records = core.records_device()                       # [planes, N_r, 6] int32, written by every encode
-    stage = [None, None]                                  # double-buffered copies of this rank's span
-    staged = [None, None]
-    gathered = [None, None]
+    # The sweeps run on compute streams of their own; the codebook gather of step k runs on torch's current stream (where
+    # the nccl backend orders its collectives) and overlaps with the sweep of step k+1.
+    computes = [torch.cuda.Stream() for _ in cores]
+    records = [c_.records_device() for c_ in cores]       # [planes, N_r, 6] int32 per context, written by its encodes
+    nbuf = 2
+    stage = [None] * nbuf                                 # copies of this rank's span where it is not contiguous in `records`
+    staged = [None] * nbuf
+    gathered = [None] * nbuf
     step_no = [0]
+    active_depth = [depth]
 
     def step():
-        k = step_no[0] & 1
+        depth = active_depth[0]
+        k = step_no[0] % nbuf
+        ci = step_no[0] % depth
         step_no[0] += 1
+        c_, compute = cores[ci], computes[ci]
         if world == 1:
-            core.encode(begin, count, compute)
+            c_.encode(begin, count, compute)
             return
         with torch.cuda.stream(compute):
             if gathered[k] is not None:
-                compute.wait_event(gathered[k])           # the gather that last read stage[k] has finished
-            core.encode(begin, count, compute)
-            # always a copy: the next encode rewrites `records` while the gather of this step is still reading
-            stage[k] = records[:, begin:begin + count].clone() if stage[k] is None else stage[k].copy_(records[:, begin:begin + count])
+                compute.wait_event(gathered[k])           # the gather that last read this buffer / context has finished
+            c_.encode(begin, count, compute)
+            src = records[ci][:, begin:begin + count]
+            if depth == nbuf and src.is_contiguous():
+                stage[k] = src                            # the context's own records: rewritten only by its next encode
+            else:
+                stage[k] = src.clone() if stage[k] is None or stage[k].data_ptr() == src.data_ptr() else stage[k].copy_(src)
             staged[k] = torch.cuda.Event()
             staged[k].record(compute)
         cur = torch.cuda.current_stream()
@@ -351,9 +371,16 @@ def main():
         gathered[k] = torch.cuda.Event()
         gathered[k].record(cur)
 
+    def sweep_times(reset=True):
+        ms = n = 0
+        for c_ in cores:                                  # contexts that did not run report (0, 0)
+            m_, n_ = c_.sweep_time(reset=reset)
+            ms, n = ms + m_, n + n_
+        return ms, n
+
     def timed(nsteps):
         torch.cuda.synchronize()
-        core.sweep_time(reset=True)
+        sweep_times()
         barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -363,10 +390,10 @@ def main():
         barrier()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-        ms, n = core.sweep_time(reset=True)
+        ms, n = sweep_times()
         return dt, ms, n
 
-    for _ in range(args.warmup):
+    for _ in range(max(args.warmup, depth) if args.warmup else 0):
         step()
     dt, sweep_ms, sweep_n = timed(args.steps)
     per_rank_sweep_ms = [sweep_ms / max(sweep_n, 1)]
@@ -391,6 +418,16 @@ def main():
     if rank == 0:
         kind = info["sweep_kind"]
         kname, operand = kernel_name(kind, B, n_iso)
+        # The clock the chip holds under this sweep (outside the timed region): k_sweep_q's own counters, shader-clock cycles
+        # over 100 MHz ticks of a sample of its waves.  Dense MFMA work is power-limited well below the 2.4 GHz the peak
+        # figures assume, so the roofline block reports the fraction against both.
+        clock_ghz = None
+        if kind == 6:
+            core.set_option("sweep_stats", 1)
+            for _ in range(max(5, min(args.steps, 20))):
+                core.encode(begin, count, computes[0])
+            clock_ghz = core.sweep_stats()["clock_ghz"]
+            core.set_option("sweep_stats", 0)
         avg_ms = sweep_ms / max(sweep_n, 1)
         pair_evals = float(ranges_per_step_rank) * Nd * n_iso
         # SURVEY 8(d)'s byte model: n+8 bytes per (range, domain) pair, one pool read per range block
@@ -424,11 +461,15 @@ def main():
                         "traffic": traffic, "traffic_note": traffic_note, "kernel": kname, "operands": operand,
                         "avg_launch_ms": avg_ms, "launches": sweep_n, "algorithmic_flop_per_launch": ops,
                         "executed_flop_per_launch": executed, "matrix_pipe_frac": executed / (avg_ms * 1e-3) / 1e12 / peak,
+                        "clock_ghz": clock_ghz, "peak_clock_ghz": PEAK_CLOCK_GHZ,
+                        "matrix_pipe_frac_at_clock": executed / (avg_ms * 1e-3) / 1e12 / (peak * clock_ghz / PEAK_CLOCK_GHZ) if clock_ghz else None,
                         "note": "achieved / frac: ALGORITHMIC flop = range blocks x N_d x n_iso x 2n per launch (SURVEY 8d: n MACs per "
                                 "pair evaluation) over the HIP-event duration of the launch on the sweep's stream, inside the timed "
                                 "region.  executed_flop / matrix_pipe_frac: what the matrix cores really issue -- the folded 8-isometry "
                                 "form needs half the MACs (DESIGN.md 4.5), so frac can exceed matrix_pipe_frac by 2x; matrix_pipe_frac "
-                                "is the utilisation against the 2.4 GHz peak (the chip holds ~1.9 GHz under this load: profiles/)"}
+                                "is the utilisation against the 2.4 GHz peak; clock_ghz is what the chip held under this kernel "
+                                "(shader-clock cycles / 100 MHz ticks of its own waves, a separate pass outside the timed region) and "
+                                "matrix_pipe_frac_at_clock the matrix-pipe utilisation at that clock"}
         else:
             # VALU instructions per pair evaluation of the sweep kernel (static count from the ISA):
             # k_sweep_fast: n/4 v_dot4 per pair evaluation, plus per (range, domain): 1 iso -> 5; 8 iso -> 15, shared by 8
@@ -456,7 +497,7 @@ def main():
             "config": {"workload": wl["desc"] if args.dist == "U" else wl["desc"].replace("synthetic grey U", f"grey {args.dist}"),
                        "dist": args.dist, "image": f"{W}x{H}", "B": B, "n_iso": n_iso, "wK": core.wK,
                        "planes_per_rank" if scaling == "weak" else "planes": planes,
-                       "N_r": Nr, "N_d": Nd, "pool_chunks": info["chunks"], "sweep_kind": kind,
+                       "N_r": Nr, "N_d": Nd, "pool_chunks": info["chunks"], "sweep_kind": kind, "pipeline_depth": depth,
                        "parallelism": f"range/plane shards x{world}"},
             "pair_evals_per_s": pair_evals * sweep_n / (sweep_ms * 1e-3) if sweep_ms > 0 else None,
             "roofline": roofline,
@@ -467,12 +508,14 @@ def main():
         }
         if world == 1 and not args.no_alt and operand is not None:
             # north_star's literal design (VALU only, no MFMA) on the same workload and buffers: reported beside, never as `value`
-            core.set_option("sweep", 5 if (B == 8 and n_iso == 8) else 2)
-            for _ in range(args.warmup):
+            for c_ in cores:
+                c_.set_option("sweep", 5 if (B == 8 and n_iso == 8) else 2)
+            for _ in range(max(args.warmup, depth)):
                 step()
             dtv, msv, nv = timed(args.steps)
             iv = core.info()
-            core.set_option("sweep", args.sweep)
+            for c_ in cores:
+                c_.set_option("sweep", args.sweep)
             out["valu_only"] = {"how": "fic_ctx_set_option(ctx, \"sweep\", 5 or 2) / FIC_SWEEP=5", "kernel": kernel_name(iv["sweep_kind"], B, n_iso)[0],
                                 "value": total_ranges / dtv, "unit": "range-block matches/s", "ms_per_step": dtv / args.steps * 1e3,
                                 "avg_launch_ms": msv / max(nv, 1), "default_speedup": dtv / dt,
@@ -480,6 +523,17 @@ def main():
                                         "north_star describes (no MFMA).  Its premise -- reduction/bandwidth-bound -- does not hold: "
                                         "profiles/r01z_cfg2_default_pmc_summary.txt shows 0.7 % of HBM peak and VALU busy 93.5 %, so the "
                                         "library default is the matrix-core sweep"}
+        if want_pipelined_leg:
+            active_depth[0] = 2
+            for _ in range(max(args.warmup, 2)):
+                step()
+            dtp, msp, npl = timed(args.steps)
+            active_depth[0] = depth
+            out["pipelined"] = {"how": "bench.py --pipeline 2: two fic_ctx on two streams take the steps alternately", "depth": 2,
+                                "value": total_ranges / dtp, "unit": "range-block matches/s", "ms_per_step": dtp / args.steps * 1e3,
+                                "avg_launch_ms": msp / max(npl, 1),
+                                "note": "same work per step; the prep kernels of step k+1 fill the ragged tail of sweep k, so the "
+                                        "launches overlap and avg_launch_ms is no longer the time one sweep needs (hence not `value`)"}
         if world == 1 and not args.no_alt and args.workload == "cfg2" and not (args.size or args.block or args.planes or args.n_iso):
             out["single_image"] = single_image(fic_amd, torch, make_image(seed), B, n_iso, local_rank, args.sweep)
         if not args.no_cpu_baseline and world == 1:

@@ -382,14 +382,22 @@ int q_sweep(fic_ctx* c, int tile0, int tile1, hipStream_t s, int* nchunks_out)
     const int ct_begin = tile0 * tsz * cpr / 32, ct_end = tile1 * tsz * cpr / 32;
     int nchunks = c->opt_chunks;
     if (nchunks <= 0) {
-        // a chunk's start-up is about one domain tile of extra work per range (fic_q.hip), so chunks only need to be
-        // long enough to hide that (>= 16 tiles) and numerous enough to fill the chip: the kernels run two workgroups per
-        // CU (VGPR-bound), i.e. 512 at a time -- two rounds of them balance the tail
+        // Two reasons to split the pool into chunks, each with its own price (a chunk starts with theta unset: until its
+        // first good candidate has been evaluated every pair of every tile is queued -- tens of tiles' worth of work):
+        //  fill:    fewer workgroups than the chip holds at once (`resident`): split until two rounds of them exist, but
+        //           keep >= 16 tiles per chunk;
+        //  balance: the kernel ends with its slowest wave, and one round of equally long waves leaves ~25 % of the
+        //           wave-cycles idle (profiles/r02w_chunk_count_sweep.txt): aim for 8 rounds, but only with chunks long
+        //           enough (>= 1024 tiles) that the start-up is noise.
         const long long base_wg = (long long)((ct_end - ct_begin + q.CT - 1) / q.CT) * g.planes;
-        long long want = (1024 + base_wg - 1) / base_wg;
-        long long cap = q.ndtiles / 16;
-        if (cap < 1) cap = 1;
-        nchunks = (int)(want < cap ? want : cap);
+        const long long resident = 256LL * fic_q_resident(g.B);
+        auto ceil_div = [](long long a, long long b) { return (a + b - 1) / b; };
+        long long fill = base_wg < resident ? ceil_div(2 * resident, base_wg) : 1;
+        if (fill > q.ndtiles / 16) fill = q.ndtiles / 16;
+        long long bal = ceil_div(8 * resident, base_wg);
+        if (bal > q.ndtiles / 1024) bal = q.ndtiles / 1024;
+        const long long nc = fill > bal ? fill : bal;
+        nchunks = (int)(nc < 1 ? 1 : nc);
     }
     if (nchunks > q.ndtiles) nchunks = q.ndtiles;
     int tiles_per_chunk = (q.ndtiles + nchunks - 1) / nchunks;
@@ -715,8 +723,8 @@ int fic_ctx_set_option(fic_ctx* c, const char* name, int value)
     } else if (!strcmp(name, "sweep_stats")) {
         HIP_TRY(hipSetDevice(c->device));
         if (value && !c->q_stats) {
-            HIP_TRY(hipMalloc((void**)&c->q_stats, 4 * sizeof(unsigned long long)));
-            HIP_TRY(hipMemset(c->q_stats, 0, 4 * sizeof(unsigned long long)));
+            HIP_TRY(hipMalloc((void**)&c->q_stats, 8 * sizeof(unsigned long long)));
+            HIP_TRY(hipMemset(c->q_stats, 0, 8 * sizeof(unsigned long long)));
         } else if (!value && c->q_stats) {
             HIP_TRY(hipStreamSynchronize(c->last_stream));
             (void)hipFree(c->q_stats);
@@ -741,15 +749,15 @@ int fic_ctx_sweep_time(fic_ctx* c, double* total_ms, int* launches, int reset)
     return FIC_OK;
 }
 
-int fic_ctx_sweep_stats(fic_ctx* c, uint64_t* out4, int reset)
+int fic_ctx_sweep_stats(fic_ctx* c, uint64_t* out8, int reset)
 {
-    if (!c || !out4) return fail(FIC_E_ARGUMENT, "fic_ctx_sweep_stats: null argument");
+    if (!c || !out8) return fail(FIC_E_ARGUMENT, "fic_ctx_sweep_stats: null argument");
     std::lock_guard<std::mutex> lk(c->mu);
     if (!c->q_stats) return fail(FIC_E_STATE, "fic_ctx_sweep_stats: set the option \"sweep_stats\" first");
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->last_stream));
-    HIP_TRY(hipMemcpy(out4, c->q_stats, 4 * sizeof(uint64_t), hipMemcpyDeviceToHost));
-    if (reset) HIP_TRY(hipMemset(c->q_stats, 0, 4 * sizeof(uint64_t)));
+    HIP_TRY(hipMemcpy(out8, c->q_stats, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    if (reset) HIP_TRY(hipMemset(c->q_stats, 0, 8 * sizeof(uint64_t)));
     return FIC_OK;
 }
 

@@ -110,6 +110,7 @@ int fic_launch_sweep_d4(const FicBuffers& b, const uint32_t* rng_d4, const uint3
 int fic_q_ct(int B);                 // column tiles (x32 columns) per workgroup
 int fic_q_cols_per_range(int B, int n_iso);   // sweep columns per range block: 1 (1 isometry), 8 (B = 4), 4 (isometry pairs, B = 8 / 16)
 int fic_q_unroll(int B, int n_iso);   // unroll factor of the sweep loop: chunks are whole multiples, the store has that many spare tiles twice
+int fic_q_resident(int B);          // workgroups of k_sweep_q a CU holds at once (chunk policy)
 int fic_launch_q_prep(const FicBuffers& b, void* poolQ, void* dflat, void* rngQ, void* rngE, void* theta_g,
                       const FicGeom& g, int ndtiles_alloc, int nct_alloc, int grp0, int ngrp, hipStream_t s);
 int fic_launch_sweep_q(const FicBuffers& b, const void* poolQ, const void* dflat, const void* rngQ, const void* rngE,

@@ -64,7 +64,19 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 #ifndef FIC_Q_CTW_B8
 #define FIC_Q_CTW_B8 4
 #endif
-__host__ __device__ constexpr int fic_q_ctw(int NK) { return NK == 4 ? FIC_Q_CTW_B8 : (NK < 4 ? 4 : 2); }   // column tiles (x32 range copies) per wave
+#ifndef FIC_Q_CTW_B4
+#define FIC_Q_CTW_B4 8
+#endif
+#ifndef FIC_Q_WPG
+#define FIC_Q_WPG 4                        // waves per workgroup of k_sweep_q (the waves are independent: no barrier, own queue)
+#endif
+#ifndef FIC_Q_WAVES_B8
+#define FIC_Q_WAVES_B8 2                   // waves per SIMD the register budget is cut for (launch bounds)
+#endif
+#ifndef FIC_Q_WAVES_B4
+#define FIC_Q_WAVES_B4 3
+#endif
+__host__ __device__ constexpr int fic_q_ctw(int NK) { return NK == 4 ? FIC_Q_CTW_B8 : (NK < 4 ? FIC_Q_CTW_B4 : 2); }   // column tiles (x32 range copies) per wave
 #define FIC_Q_UNROLL 2                     // domain tiles per iteration of the sweep loop (two fragment buffers swap roles)
 
 // two floats -> packed f16 pair (round to nearest even), element 0 in the low half
@@ -307,7 +319,8 @@ struct QArgs {
     const float* rngE;
     unsigned long long* key;
     uint32_t* theta_g;               // [plane][Nr_pad] best published level per range (order-preserving integer image; 0 = none)
-    unsigned long long* stats;       // optional [4]: tile epilogues, tiles with flagged pairs, queued entries, waves
+    unsigned long long* stats;       // optional [8]: tile epilogues, tiles with flagged pairs, queued entries, waves; of every
+                                     //   64th wave: shader-clock cycles and 100 MHz ticks it was alive (summed), their number
     int Nd, Nd_pad, Nr, Nr_pad, n, lgn, W, H, Rw;
     int ndtiles, ndtiles_loop, ndtiles_alloc, nct_alloc;   // ndtiles_loop: ndtiles rounded up to the loop's unroll factor
     int ct_begin, ct_end;            // column tiles (x32 columns) of this shard
@@ -319,14 +332,17 @@ __device__ __forceinline__ v16f mfma_f16(v4i a, v4i b, v16f c)
 {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
+// Every node is a three-input maximum (v_max3_f32 with |.| source modifiers): a two-input fmaxf of MFMA results costs two
+// extra canonicalising v_max_f32 x, x under IEEE mode, hence the constant 0 as third operand at the root.
+__device__ __forceinline__ float max3f(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
 __device__ __forceinline__ float max16_abs(const v16f& a)
 {
-    const float m0 = fmaxf(fmaxf(fabsf(a[0]), fabsf(a[1])), fabsf(a[2]));
-    const float m1 = fmaxf(fmaxf(fabsf(a[3]), fabsf(a[4])), fabsf(a[5]));
-    const float m2 = fmaxf(fmaxf(fabsf(a[6]), fabsf(a[7])), fabsf(a[8]));
-    const float m3 = fmaxf(fmaxf(fabsf(a[9]), fabsf(a[10])), fabsf(a[11]));
-    const float m4 = fmaxf(fmaxf(fabsf(a[12]), fabsf(a[13])), fabsf(a[14]));
-    return fmaxf(fmaxf(fmaxf(m0, m1), m2), fmaxf(fmaxf(m3, m4), fabsf(a[15])));
+    const float m0 = max3f(fabsf(a[0]), fabsf(a[1]), fabsf(a[2]));
+    const float m1 = max3f(fabsf(a[3]), fabsf(a[4]), fabsf(a[5]));
+    const float m2 = max3f(fabsf(a[6]), fabsf(a[7]), fabsf(a[8]));
+    const float m3 = max3f(fabsf(a[9]), fabsf(a[10]), fabsf(a[11]));
+    const float m4 = max3f(fabsf(a[12]), fabsf(a[13]), fabsf(a[14]));
+    return max3f(max3f(m0, m1, m2), max3f(m3, m4, fabsf(a[15])), 0.0f);
 }
 // MODE 2: |even| + |odd| per element, then the maximum
 __device__ __forceinline__ float max16_sum(const v16f& a, const v16f& b)
@@ -404,14 +420,17 @@ __device__ __forceinline__ float q_share_max(float v)
     return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
 }
 
+// Launch bounds: asking for two waves per SIMD at B = 4 / 8 caps the kernel at the 256 architectural VGPRs, and only then does
+// the compiler emit the MFMAs with VGPR destinations; without the cap every accumulator lands in an AGPR and each element
+// the epilogue tests costs a v_accvgpr_read first (16-32 extra VALU issues per tile: more than the epilogue itself).
 template <int NK, int MODE>
-__global__ __launch_bounds__(256) void k_sweep_q(QArgs A)
+__global__ __launch_bounds__(64 * FIC_Q_WPG, NK == 4 ? FIC_Q_WAVES_B8 : (NK < 4 ? FIC_Q_WAVES_B4 : 1)) void k_sweep_q(QArgs A)
 {
-    constexpr int CTW = fic_q_ctw(NK), CT = 4 * CTW;
+    constexpr int CTW = fic_q_ctw(NK), CT = FIC_Q_WPG * CTW;
     constexpr int CSHIFT = QMode<MODE>::CSHIFT;
     constexpr bool FOLD = MODE == 2;
     constexpr int NKA = FOLD ? NK / 2 : NK;                  // MFMA steps per accumulator
-    __shared__ uint32_t sQ[4][FIC_Q_QCAP];             // per wave: domain block | column-in-wave << 24
+    __shared__ uint32_t sQ[FIC_Q_WPG][FIC_Q_QCAP];             // per wave: domain block | column-in-wave << 24
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     int combo_, gx_;
@@ -423,6 +442,7 @@ __global__ __launch_bounds__(256) void k_sweep_q(QArgs A)
     int dt1 = dt0 + A.tiles_per_chunk;                       // the last chunk runs into the store's zero tiles (flagged flat)
     if (dt1 > A.ndtiles_loop) dt1 = A.ndtiles_loop;
     if (dt0 >= A.ndtiles || ctw0 >= A.ct_end) return;        // (no barrier in this kernel: waves are independent)
+    const unsigned long long clk0 = A.stats ? clock64() : 0ull, tick0 = A.stats ? wall_clock64() : 0ull;
     int nci = A.ct_end - ctw0;                               // column tiles this wave really owns (wave-uniform)
     if (nci > CTW) nci = CTW;
 
@@ -570,7 +590,7 @@ __global__ __launch_bounds__(256) void k_sweep_q(QArgs A)
             const float mx = FOLD ? max16_sum(acc, acc2) : max16_abs(acc);
             const bool hit = mx > tau[ci];
             if constexpr (NK == 4 && !FOLD) {
-                // M M v v v M v v v M v v v v v: the epilogue reads a tile whose last MFMA was issued >= 64 cycles ago
+                // M M v v v M v v v M v v v (8 x v_max3 + compare): the epilogue reads a tile whose last MFMA was issued >= 64 cycles ago
                 __builtin_amdgcn_sched_group_barrier(0x8, 2, 0);
                 __builtin_amdgcn_sched_group_barrier(0x2, 3, 0);
                 __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
@@ -619,17 +639,24 @@ __global__ __launch_bounds__(256) void k_sweep_q(QArgs A)
         atomicAdd(&A.stats[1], (unsigned long long)st_slow);
         atomicAdd(&A.stats[2], (unsigned long long)st_pairs);
         atomicAdd(&A.stats[3], 1ull);
+        if ((blockIdx.x & 15) == 0 && wave == 0) {          // a sample: same-address atomics serialise
+            atomicAdd(&A.stats[4], (unsigned long long)(clock64() - clk0));
+            atomicAdd(&A.stats[5], (unsigned long long)(wall_clock64() - tick0));
+            atomicAdd(&A.stats[6], 1ull);
+        }
     }
 }
 
 // ---------------------------------------------------------------------------------------------
 // host-side launchers
 // ---------------------------------------------------------------------------------------------
-int fic_q_ct(int B) { return 4 * fic_q_ctw(B * B / 16); }       // column tiles (x32 columns) per workgroup
+int fic_q_ct(int B) { return FIC_Q_WPG * fic_q_ctw(B * B / 16); }       // column tiles (x32 columns) per workgroup
 // 0: 1 isometry; 1: 8 isometries, one column per copy; 2: 8 isometries folded into 4 columns per range block
 int fic_q_mode(int B, int n_iso) { return n_iso == 1 ? 0 : (B == 4 ? 1 : 2); }
 int fic_q_cols_per_range(int B, int n_iso) { const int m = fic_q_mode(B, n_iso); return m == 0 ? 1 : (m == 1 ? 8 : 4); }
 int fic_q_unroll(int B, int n_iso) { (void)B; (void)n_iso; return FIC_Q_UNROLL; }
+// workgroups of k_sweep_q a CU holds at once (a workgroup puts one wave on each SIMD; VGPR-bound)
+int fic_q_resident(int B) { return (B == 4 ? FIC_Q_WAVES_B4 : (B == 8 ? FIC_Q_WAVES_B8 : 1)) * 4 / FIC_Q_WPG; }
 
 int fic_launch_q_prep(const FicBuffers& b, void* poolQ, void* dflat, void* rngQ, void* rngE, void* theta_g,
                       const FicGeom& g, int ndtiles_alloc, int nct_alloc, int grp0, int ngrp, hipStream_t s)
@@ -663,7 +690,7 @@ int fic_launch_sweep_q(const FicBuffers& b, const void* poolQ, const void* dflat
     // the loop reads up to ndtiles_loop + prefetch distance tiles; chunks must be whole unrolled iterations
     if (ct_begin + A.nctg * CT > nct_alloc || g.Nd >= (1 << 24) || A.ndtiles_loop + unroll > ndtiles_alloc || tiles_per_chunk % unroll)
         return (int)hipErrorInvalidValue;
-    dim3 grid((unsigned)(nchunks * g.planes) * (unsigned)A.nctg), block(256);
+    dim3 grid((unsigned)(nchunks * g.planes) * (unsigned)A.nctg), block(64 * FIC_Q_WPG);
     const int mode = fic_q_mode(g.B, g.n_iso);
     if (g.B == 4 && mode == 0) hipLaunchKernelGGL((k_sweep_q<1, 0>), grid, block, 0, s, A);
     else if (g.B == 4 && mode == 1) hipLaunchKernelGGL((k_sweep_q<1, 1>), grid, block, 0, s, A);

@@ -128,10 +128,13 @@ class Encoder:
         return ms.value, n.value
 
     def sweep_stats(self, reset=True):
-        """k_sweep_q counters (after set_option("sweep_stats", 1)): tile epilogues, flagged tiles, exact pairs, waves."""
-        v = (C.c_uint64 * 4)()
+        """k_sweep_q counters (after set_option("sweep_stats", 1)): tile epilogues, flagged tiles, exact pairs, waves,
+        and of a sample of the waves the shader-clock cycles / 100 MHz ticks they lived (`clock_ghz` = their ratio)."""
+        v = (C.c_uint64 * 8)()
         capi.check(capi.lib().fic_ctx_sweep_stats(self._h, v, 1 if reset else 0))
-        return dict(zip(["tiles", "flagged_tiles", "exact_pairs", "waves"], [int(x) for x in v]))
+        d = dict(zip(["tiles", "flagged_tiles", "exact_pairs", "waves", "wave_cycles", "wave_ticks", "waves_sampled"], [int(x) for x in v]))
+        d["clock_ghz"] = d["wave_cycles"] / d["wave_ticks"] / 10.0 if d["wave_ticks"] else None
+        return d
 
     def info(self):
         v = (C.c_int * 10)()

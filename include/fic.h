@@ -216,8 +216,10 @@ FIC_API int fic_ctx_set_option(fic_ctx* ctx, const char* name, int value);
 FIC_API int fic_ctx_sweep_time(fic_ctx* ctx, double* total_ms, int* launches, int reset);
 /* Counters of the default sweep k_sweep_q since the last reset (option "sweep_stats" = 1 first): out[0] tile epilogues
  * (32 range copies x 32 domain blocks each), out[1] tiles that had flagged pairs, out[2] pairs evaluated exactly,
- * out[3] waves.  Synchronises the context's stream. */
-FIC_API int fic_ctx_sweep_stats(fic_ctx* ctx, uint64_t* out4, int reset);
+ * out[3] waves; of a sample of the waves: out[4] shader-clock cycles and out[5] 100 MHz ticks they were alive (summed),
+ * out[6] their number (out[4] / out[5] / 10 = the clock in GHz the chip held under this kernel); out[7] reserved.
+ * Synchronises the context's stream. */
+FIC_API int fic_ctx_sweep_stats(fic_ctx* ctx, uint64_t* out8, int reset);
 /* Geometry actually in use: out[0..9] = Rw, Rh, N_r, Dw, Dh, N_d, NR, tiles, chunks, sweep kind. */
 FIC_API int fic_ctx_info(fic_ctx* ctx, int* out10);
 

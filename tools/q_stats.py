@@ -47,7 +47,8 @@ def run(W, B, n_iso, planes, dist="U", sweep=6, chunks=0, reps=5):
     if st:
         msg += (f", cycles/tile@2.4GHz={ms / n * 1e-3 * 2.4e9 * 1024 / max(tiles, 1):.0f} (floor {32 * nk}), "
                 f"flagged_tiles={st['flagged_tiles'] / max(st['tiles'], 1):.4f}, "
-                f"exact_pairs/range={st['exact_pairs'] / reps / (planes * enc.n_ranges):.1f}, waves={st['waves'] // reps}")
+                f"exact_pairs/range={st['exact_pairs'] / reps / (planes * enc.n_ranges):.1f}, waves={st['waves'] // reps}, "
+                f"clock={st['clock_ghz'] or 0:.3f} GHz, wave_alive={st['wave_ticks'] * 1e-8 / max(st['waves_sampled'], 1) / (ms / n * 1e-3):.2f} of sweep")
     print(msg, flush=True)
     enc.close()
 
