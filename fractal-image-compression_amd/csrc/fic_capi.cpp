@@ -80,7 +80,7 @@ int ctx_free_all(fic_ctx* c)
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
     c->ev.clear();
     if (c->own_stream) { (void)hipStreamDestroy(c->own_stream); c->own_stream = nullptr; }
-    void* ptrs[] = {c->gray_own, c->argb_stage, c->collage, c->decoded, c->dec_state, c->dec_sq, c->mfma_poolB, c->mfma_rngA, c->mfma_sw, c->mfma_rconst, c->q_pool, c->q_flat, c->q_rng, c->q_E, c->q_thg, c->q_stats, c->d4_rng, c->d4_pool, c->b.scaled, c->b.pool_pix, c->b.pool_st, c->b.pool_var,
+    void* ptrs[] = {c->gray_own, c->argb_stage, c->collage, c->decoded, c->dec_state, c->dec_sq, c->mfma_poolB, c->mfma_rngA, c->mfma_sw, c->mfma_rconst, c->q_pool, c->q_flat, c->q_rng, c->q_rngC, c->q_E, c->q_thg, c->q_stats, c->d4_rng, c->d4_pool, c->b.scaled, c->b.pool_pix, c->b.pool_st, c->b.pool_var,
                     c->b.pool_s64, c->b.rng_pix, c->b.rng_st, c->b.key, c->o.idx_local, c->o.idx_global, c->o.iso,
                     c->o.a, c->o.b, c->o.err, c->o.qrows, c->o.records};
     for (void* p : ptrs)
@@ -365,11 +365,12 @@ int q_prep(fic_ctx* c, int tile0, int tile1, hipStream_t s)
         HIP_TRY(hipMalloc(&c->q_rng, P * q.nct_alloc * NK * 64 * 16));
         HIP_TRY(hipMemsetAsync(c->q_rng, 0, P * q.nct_alloc * NK * 64 * 16, s));
     }
+    if (!c->q_rngC) HIP_TRY(hipMalloc(&c->q_rngC, P * g.Nr_pad * fic_q_cols_per_range(g.B, g.n_iso) * g.n));
     if (!c->q_E) HIP_TRY(hipMalloc(&c->q_E, P * g.Nr_pad * sizeof(float)));
     if (!c->q_thg) HIP_TRY(hipMalloc(&c->q_thg, P * g.Nr_pad * sizeof(uint32_t)));
     const int tsz = 64 * g.NR;
     const int grp0 = tile0 * tsz / 64, grp1 = tile1 * tsz / 64;      // 64-range groups covering the span
-    if (fic_launch_q_prep(c->b, c->q_pool, c->q_flat, c->q_rng, c->q_E, c->q_thg, g, q.ndtiles_alloc, q.nct_alloc, grp0, grp1 - grp0, s))
+    if (fic_launch_q_prep(c->b, c->q_pool, c->q_flat, c->q_rng, c->q_rngC, c->q_E, c->q_thg, g, q.ndtiles_alloc, q.nct_alloc, grp0, grp1 - grp0, s))
         return fail(FIC_E_HIP, "k_pool_q / k_range_q launch failed");
     return FIC_OK;
 }
@@ -403,7 +404,7 @@ int q_sweep(fic_ctx* c, int tile0, int tile1, hipStream_t s, int* nchunks_out)
     int tiles_per_chunk = (q.ndtiles + nchunks - 1) / nchunks;
     tiles_per_chunk = (tiles_per_chunk + q.unroll - 1) / q.unroll * q.unroll;     // whole iterations of the unrolled sweep loop
     nchunks = (q.ndtiles + tiles_per_chunk - 1) / tiles_per_chunk;
-    if (fic_launch_sweep_q(c->b, c->q_pool, c->q_flat, c->q_rng, c->q_E, c->q_thg, g, ct_begin, ct_end, q.ndtiles, q.ndtiles_alloc,
+    if (fic_launch_sweep_q(c->b, c->q_pool, c->q_flat, c->q_rng, c->q_rngC, c->q_E, c->q_thg, g, ct_begin, ct_end, q.ndtiles, q.ndtiles_alloc,
                            q.nct_alloc, tiles_per_chunk, nchunks, s, c->q_stats))
         return fail(FIC_E_HIP, "k_sweep_q launch failed");
     *nchunks_out = nchunks;

@@ -78,6 +78,7 @@ struct fic_ctx {
     void* q_pool = nullptr;          // k_sweep_q ("sweep" = 6): A fragments, flat-tile flags, B fragments, error bounds, published theta
     void* q_flat = nullptr;
     void* q_rng = nullptr;
+    void* q_rngC = nullptr;                  // the sweep columns' isometry copies as bytes (exact evaluation of flagged pairs)
     void* q_E = nullptr;
     void* q_thg = nullptr;
     unsigned long long* q_stats = nullptr;   // "sweep_stats" = 1: device counters of k_sweep_q (fic_ctx_sweep_stats)

@@ -111,9 +111,9 @@ int fic_q_ct(int B);                 // column tiles (x32 columns) per workgroup
 int fic_q_cols_per_range(int B, int n_iso);   // sweep columns per range block: 1 (1 isometry), 8 (B = 4), 4 (isometry pairs, B = 8 / 16)
 int fic_q_unroll(int B, int n_iso);   // unroll factor of the sweep loop: chunks are whole multiples, the store has that many spare tiles twice
 int fic_q_resident(int B);          // workgroups of k_sweep_q a CU holds at once (chunk policy)
-int fic_launch_q_prep(const FicBuffers& b, void* poolQ, void* dflat, void* rngQ, void* rngE, void* theta_g,
+int fic_launch_q_prep(const FicBuffers& b, void* poolQ, void* dflat, void* rngQ, void* rngC, void* rngE, void* theta_g,
                       const FicGeom& g, int ndtiles_alloc, int nct_alloc, int grp0, int ngrp, hipStream_t s);
-int fic_launch_sweep_q(const FicBuffers& b, const void* poolQ, const void* dflat, const void* rngQ, const void* rngE,
+int fic_launch_sweep_q(const FicBuffers& b, const void* poolQ, const void* dflat, const void* rngQ, const void* rngC, const void* rngE,
                        void* theta_g, const FicGeom& g, int ct_begin, int ct_end, int ndtiles, int ndtiles_alloc,
                        int nct_alloc, int tiles_per_chunk, int nchunks, hipStream_t s, unsigned long long* stats = nullptr);
 int fic_launch_decode_iteration_rgb(int32_t* scaled, int32_t* image, const int32_t* qrows5, FicDecodeState* state,

@@ -192,6 +192,7 @@ __global__ __launch_bounds__(256) void k_pool_q(const uint8_t* __restrict__ scal
 // FC:67-73 (rM = sum / n, int), rem = sum - n*rM (= varianzRange after the loop at FC:665-672), the error bound E_r, the
 // reset of the search key and of the published theta, and the B fragments for k_sweep_q.
 //   copy_k[pos] = r[iso_source(iso_inverse(k), pos)]  so that  dot(copy_k, d) == dot(r, iso_k(d))   
+//   (also stored as plain bytes, rngC, for the exact evaluation of the pairs the sweep flags)
 //   column rr of the sweep: mode 0 (1 isometry): range rr; mode 1 (8 isometries, direct): range rr >> 3, copy rr & 7;
 //   mode 2 (8 isometries, folded): range rr >> 2, isometry pair rr & 3 = {0,2}, {1,3}, {4,5}, {6,7}.
 //   rngQ[plane][ctile][m][lane] = 8 f16 of column 32*ctile + (lane&31), h = lane>>5: centred pixels [16m + 8h, +8) of the
@@ -200,8 +201,8 @@ __global__ __launch_bounds__(256) void k_pool_q(const uint8_t* __restrict__ scal
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_range_q(const uint8_t* __restrict__ gray, FicRngStat* __restrict__ rng_st,
                                                  float* __restrict__ rngE, unsigned long long* __restrict__ key,
-                                                 uint32_t* __restrict__ theta_g, v4i* __restrict__ rngQ, FicGeom g,
-                                                 int nct_alloc, int grp0, int mode)
+                                                 uint32_t* __restrict__ theta_g, v4i* __restrict__ rngQ,
+                                                 uint32_t* __restrict__ rngC, FicGeom g, int nct_alloc, int grp0, int mode)
 {
     __shared__ __attribute__((aligned(16))) uint8_t blk[64 * (256 + 4)];
     __shared__ int s_rM[64];
@@ -293,6 +294,24 @@ __global__ __launch_bounds__(256) void k_range_q(const uint8_t* __restrict__ gra
         for (int u = 0; u < 4; u++) v[u] = real ? f16_pair((float)a[2 * u], (float)a[2 * u + 1]) : 0;
         if (ct0 + ctl < nct_alloc) rngQ[((size_t)plane * nct_alloc + ct0 + ctl) * NK * 64 + (size_t)m * 64 + lane] = v;
     }
+    // the same copies as bytes, n per column, for the exact evaluation of the flagged pairs (q_flush): rngC[plane][column][n]
+    for (int t = threadIdx.x; t < cols * DW; t += 256) {
+        const int col = t / DW, wd = t % DW;
+        const int l = col >> lgc, c = col & (cpr - 1);
+        if (j0 + l >= g.Nr_pad) break;
+        const int k = mode == 2 ? (c == 0 ? 0 : (c == 1 ? 1 : (c == 2 ? 4 : 6))) : c;
+        int ax, bx, cx, ay, by, cy;
+        iso_affine(iso_inverse(k), B - 1, ax, bx, cx, ay, by, cy);
+        const int s0 = cx + cy * B, sx = ax + ay * B, sy = bx + by * B;
+        const uint8_t* b = blk + l * stride;
+        uint32_t w = 0;
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int p = 4 * wd + u;
+            w |= (uint32_t)b[s0 + sx * (p & (B - 1)) + sy * (p >> lgB)] << (8 * u);
+        }
+        rngC[((size_t)plane * g.Nr_pad * cpr + (size_t)j0 * cpr + col) * DW + wd] = w;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -314,7 +333,7 @@ struct QArgs {
     const FicDomStat* pool_st;
     const double* pool_s64;
     const v4i* rngQ;                 // [plane][nct_alloc][NK][64]
-    const uint8_t* gray;             // [plane][H][W] the input image: range pixels of the exact path are gathered from it
+    const uint32_t* rngC;            // [plane][Nr_pad * columns per range][n] the columns' isometry copies as bytes (exact path)
     const FicRngStat* rng_st;
     const float* rngE;
     unsigned long long* key;
@@ -375,7 +394,7 @@ __device__ __forceinline__ void q_flush(const QArgs& A, const uint32_t* myq, int
     const double* p64 = A.pool_s64 + (size_t)plane * A.Nd_pad;
     const FicDomStat* pst = A.pool_st + (size_t)plane * A.Nd_pad;
     unsigned long long* keyp = A.key + (size_t)plane * A.Nr_pad;
-    const uint8_t* img = A.gray + (size_t)plane * A.W * A.H;
+    const uint32_t* cop = A.rngC + (size_t)plane * A.Nr_pad * (1 << CSHIFT) * (A.n / 4);
     for (int base = 0; base < qn; base += 64) {
         const int i = base + lane;
         if (i < qn) {
@@ -385,12 +404,29 @@ __device__ __forceinline__ void q_flush(const QArgs& A, const uint32_t* myq, int
             const int col = ctw0 * 32 + (int)(ent >> 24);
             const int j = col >> CSHIFT, k = q_col_iso<MODE>(col & ((1 << CSHIFT) - 1));
             const int k2 = k == 0 ? 2 : (k == 1 ? 3 : k + 1);                       // MODE 2: the pair's second isometry
-            const uint8_t* blk = img + (size_t)((j / A.Rw) * B) * A.W + (j % A.Rw) * B;
             const FicRngStat rs = rst[j];
             const int Sd = (int)pst[d].sum;
             const double s64 = p64[d];
-            uint32_t s, s2;
-            iso_dot<B, MODE == 2>(blk, A.W, k, (const uint32_t*)(A.pool_pix + ((size_t)plane * A.Nd_pad + d) * A.n), s, s2);
+            // sum copy_k[pos] d[pos]; the partner copy is the point reflection: sum copy_k[n-1-pos] d[pos] = sum_q copy_k[q]
+            // d[n-1-q], i.e. the mirrored dword of the domain block with its bytes reversed
+            const uint4* cw = (const uint4*)(cop + (size_t)col * (B * B / 4));
+            const uint4* dw = (const uint4*)(A.pool_pix + ((size_t)plane * A.Nd_pad + d) * A.n);
+            uint32_t s = 0, s2 = 0;
+#pragma unroll
+            for (int q = 0; q < B * B / 16; q++) {
+                const uint4 c4 = cw[q], d4 = dw[q];
+                s = __builtin_amdgcn_udot4(c4.x, d4.x, s, false);
+                s = __builtin_amdgcn_udot4(c4.y, d4.y, s, false);
+                s = __builtin_amdgcn_udot4(c4.z, d4.z, s, false);
+                s = __builtin_amdgcn_udot4(c4.w, d4.w, s, false);
+                if constexpr (MODE == 2) {
+                    const uint4 m4 = dw[B * B / 16 - 1 - q];
+                    s2 = __builtin_amdgcn_udot4(c4.x, __builtin_bswap32(m4.w), s2, false);
+                    s2 = __builtin_amdgcn_udot4(c4.y, __builtin_bswap32(m4.z), s2, false);
+                    s2 = __builtin_amdgcn_udot4(c4.z, __builtin_bswap32(m4.y), s2, false);
+                    s2 = __builtin_amdgcn_udot4(c4.w, __builtin_bswap32(m4.x), s2, false);
+                }
+            }
             const int base_c = rs.rM * Sd + (Sd >> A.lgn) * rs.rem;
             const float err = exact_error((int)s - base_c, rs.rem, s64);
             unsigned long long best = ((unsigned long long)f32_orderable(err) << 32) | (d * (uint32_t)NISO + (uint32_t)k);
@@ -658,7 +694,7 @@ int fic_q_unroll(int B, int n_iso) { (void)B; (void)n_iso; return FIC_Q_UNROLL; 
 // workgroups of k_sweep_q a CU holds at once (a workgroup puts one wave on each SIMD; VGPR-bound)
 int fic_q_resident(int B) { return (B == 4 ? FIC_Q_WAVES_B4 : (B == 8 ? FIC_Q_WAVES_B8 : 1)) * 4 / FIC_Q_WPG; }
 
-int fic_launch_q_prep(const FicBuffers& b, void* poolQ, void* dflat, void* rngQ, void* rngE, void* theta_g,
+int fic_launch_q_prep(const FicBuffers& b, void* poolQ, void* dflat, void* rngQ, void* rngC, void* rngE, void* theta_g,
                       const FicGeom& g, int ndtiles_alloc, int nct_alloc, int grp0, int ngrp, hipStream_t s)
 {
     const int mode = fic_q_mode(g.B, g.n_iso);
@@ -666,19 +702,19 @@ int fic_launch_q_prep(const FicBuffers& b, void* poolQ, void* dflat, void* rngQ,
                        b.pool_st, b.pool_var, b.pool_s64, (v4i*)poolQ, (uint32_t*)dflat, g, ndtiles_alloc, mode == 2 ? 1 : 0);
     FIC_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_range_q, dim3(ngrp, g.planes), dim3(256), 0, s, (const uint8_t*)b.gray, b.rng_st, (float*)rngE, b.key,
-                       (uint32_t*)theta_g, (v4i*)rngQ, g, nct_alloc, grp0, mode);
+                       (uint32_t*)theta_g, (v4i*)rngQ, (uint32_t*)rngC, g, nct_alloc, grp0, mode);
     FIC_LAUNCH_CHECK();
     return 0;
 }
 
-int fic_launch_sweep_q(const FicBuffers& b, const void* poolQ, const void* dflat, const void* rngQ, const void* rngE,
+int fic_launch_sweep_q(const FicBuffers& b, const void* poolQ, const void* dflat, const void* rngQ, const void* rngC, const void* rngE,
                        void* theta_g, const FicGeom& g, int ct_begin, int ct_end, int ndtiles, int ndtiles_alloc,
                        int nct_alloc, int tiles_per_chunk, int nchunks, hipStream_t s, unsigned long long* stats)
 {
     QArgs A;
     A.stats = stats;
     A.poolQ = (const v4i*)poolQ; A.dflat = (const uint32_t*)dflat; A.pool_pix = b.pool_pix; A.pool_st = b.pool_st;
-    A.pool_s64 = b.pool_s64; A.rngQ = (const v4i*)rngQ; A.gray = b.gray; A.rng_st = b.rng_st;
+    A.pool_s64 = b.pool_s64; A.rngQ = (const v4i*)rngQ; A.rngC = (const uint32_t*)rngC; A.rng_st = b.rng_st;
     A.rngE = (const float*)rngE; A.key = b.key; A.theta_g = (uint32_t*)theta_g;
     A.Nd = g.Nd; A.Nd_pad = g.Nd_pad; A.Nr = g.Nr; A.Nr_pad = g.Nr_pad; A.n = g.n; A.lgn = g.lgn; A.W = g.W; A.H = g.H; A.Rw = g.Rw;
     const int unroll = fic_q_unroll(g.B, g.n_iso);
