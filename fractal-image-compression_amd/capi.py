@@ -92,6 +92,8 @@ def lib():
         "fic_rgb_ctx_set_argb_device": (C.c_int, [vp, vp]),
         "fic_rgb_ctx_encode": (C.c_int, [vp, C.c_int, vp]),
         "fic_rgb_ctx_sync": (C.c_int, [vp]),
+        "fic_rgb_ctx_set_option": (C.c_int, [vp, C.c_char_p, C.c_int]),
+        "fic_rgb_ctx_last_sweep": (C.c_int, [vp]),
         "fic_rgb_ctx_get_results_host": (C.c_int, [vp, i32p, f32p, f32p, f32p, f32p, i32p, i32p]),
         "fic_rgb_ctx_decode_host": (C.c_int, [vp, i32p, f32p, ip]),
         "fic_write_run_rgb": (C.c_int64, [i32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, u8p, C.c_int64]),
@@ -275,6 +277,13 @@ class RgbEncoder:
 
     def sync(self):
         check(lib().fic_rgb_ctx_sync(self._h))
+
+    def set_option(self, name, value):
+        """"sweep": 0 auto, 1 the VALU sweeps, 2 the matrix-core full search."""
+        check(lib().fic_rgb_ctx_set_option(self._h, name.encode(), int(value)))
+
+    def last_sweep(self):
+        return check(lib().fic_rgb_ctx_last_sweep(self._h))
 
     def results(self):
         P, N = self.planes, self.n_ranges

@@ -28,6 +28,9 @@ struct fic_rgb_ctx {
     int32_t* dec_scaled = nullptr;
     FicDecodeState* dec_state = nullptr;
     uint32_t* dec_sq = nullptr;
+    FicRgbQ q;                       // matrix-core full search (allocated on first use; one image at a time, stream-ordered)
+    int opt_sweep = 0;               // 0 auto, 1 VALU sweeps, 2 matrix-core full search
+    int last_sweep = 0;              // what the last encode ran: 1 / 2
     bool have_input = false, encoded_any = false, have_collage = false;
     hipStream_t last_stream = nullptr;
     std::mutex mu;
@@ -38,7 +41,8 @@ void rgb_free_all(fic_rgb_ctx* c)
 {
     (void)hipSetDevice(c->device);
     void* ptrs[] = {c->argb_own, c->scaled, c->pool_sum, c->pool_cf, c->pool_st, c->rng_t, c->rng_st, c->key, c->idx_local,
-                    c->idx_global, c->qrows, c->collage, c->a, c->bR, c->bG, c->bB, c->dec_image, c->dec_scaled, c->dec_state, c->dec_sq};
+                    c->idx_global, c->qrows, c->collage, c->a, c->bR, c->bG, c->bB, c->dec_image, c->dec_scaled, c->dec_state, c->dec_sq,
+                    c->q.poolQ, c->q.dflat, c->q.rngQ, c->q.qst, c->q.rngE, c->q.theta_g, c->q.amax};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
 }
@@ -62,6 +66,48 @@ void rgb_plane(const fic_rgb_ctx* c, int p, FicRgbBuffers* b, FicRgbOutputs* o)
     o->bG = c->bG + P * nr;
     o->bB = c->bB + P * nr;
     o->qrows = c->qrows + P * nr * 5;
+}
+// buffers and chunking of the matrix-core full search (same shapes and chunk policy as the grey q sweep)
+int rgb_q_setup(fic_rgb_ctx* c)
+{
+    const FicGeom& g = c->g;
+    FicRgbQ& q = c->q;
+    if (q.poolQ) return FIC_OK;
+    const int unroll = fic_q_unroll(g.B, 1), CT = fic_q_ct(g.B);
+    const size_t NK = (size_t)g.n / 16;
+    q.ndtiles = (g.Nd + 31) / 32;
+    q.ndtiles_alloc = q.ndtiles + 2 * unroll;
+    const int nct = (g.Nr + 31) / 32;
+    q.nct_alloc = ((nct + CT - 1) / CT * CT + CT + 1) & ~1;
+    const long long base_wg = (nct + CT - 1) / CT;
+    const long long resident = 256LL * fic_q_resident(g.B);
+    auto ceil_div = [](long long a, long long b) { return (a + b - 1) / b; };
+    long long fill = base_wg < resident ? ceil_div(2 * resident, base_wg) : 1;
+    if (fill > q.ndtiles / 16) fill = q.ndtiles / 16;
+    long long bal = ceil_div(8 * resident, base_wg);
+    if (bal > q.ndtiles / 1024) bal = q.ndtiles / 1024;
+    long long nc = fill > bal ? fill : bal;
+    if (nc < 1) nc = 1;
+    int tpc = (int)((q.ndtiles + nc - 1) / nc);
+    tpc = (tpc + unroll - 1) / unroll * unroll;
+    q.tiles_per_chunk = tpc;
+    q.nchunks = (q.ndtiles + tpc - 1) / tpc;
+    int rc = FIC_OK;
+    auto A = [&](hipError_t e) { if (rc == FIC_OK && e != hipSuccess) rc = fail(FIC_E_HIP, "RGB matrix-core buffers: %s", hipGetErrorString(e)); };
+    A(hipMalloc(&q.poolQ, (size_t)q.ndtiles_alloc * NK * 64 * 16));
+    A(hipMalloc(&q.dflat, (size_t)q.ndtiles_alloc * sizeof(uint32_t)));
+    A(hipMalloc(&q.rngQ, (size_t)q.nct_alloc * NK * 64 * 16));
+    A(hipMalloc(&q.qst, (size_t)g.Nr * sizeof(FicRngStat)));
+    A(hipMalloc(&q.rngE, (size_t)g.Nr * sizeof(float)));
+    A(hipMalloc(&q.theta_g, (size_t)g.Nr * sizeof(uint32_t)));
+    A(hipMalloc(&q.amax, 256));
+    if (rc != FIC_OK) {
+        void* ptrs[] = {q.poolQ, q.dflat, q.rngQ, q.qst, q.rngE, q.theta_g, q.amax};
+        for (void* p : ptrs)
+            if (p) (void)hipFree(p);
+        q = FicRgbQ();
+    }
+    return rc;
 }
 // idle single-image contexts of the one-shot RGB entry, most recently used last
 std::mutex g_rgb_mu;
@@ -148,16 +194,42 @@ int fic_rgb_ctx_encode(fic_rgb_ctx* c, int with_collage, void* hip_stream)
     const FicGeom& g = c->g;
     FicGeom g1 = g;
     g1.planes = 1;
+    // Full search: the matrix-core sweep where it pays (its prep costs ~50 us; the VALU sweep does ~1e11 pairs/s), or where
+    // the VALU full-search kernel does not exist (B = 16).  FIC_RGB_SWEEP=1|2 / option "sweep" override.
+    int want = c->opt_sweep;
+    if (const char* env = getenv("FIC_RGB_SWEEP"))
+        if (env[0] >= '1' && env[0] <= '2' && !env[1]) want = env[0] - '0';
+    const bool use_q = g.full && (want == 2 || (want == 0 && ((double)g.Nr * g.Nd >= 3e7 || g.B == 16)));
+    if (use_q && rgb_q_setup(c)) return FIC_E_HIP;
+    c->last_sweep = use_q ? 2 : 1;
     for (int p = 0; p < g.planes; p++) {
         FicRgbBuffers b;
         FicRgbOutputs o;
         rgb_plane(c, p, &b, &o);
-        if (fic_launch_rgb_encode(b, o, with_collage ? c->collage + (size_t)p * g.W * g.H : nullptr, g1, s))
+        if (fic_launch_rgb_encode(b, o, with_collage ? c->collage + (size_t)p * g.W * g.H : nullptr, g1, s, use_q ? &c->q : nullptr))
             return fail(FIC_E_HIP, "RGB kernel launch failed (plane %d)", p);
     }
     c->encoded_any = true;
     c->have_collage = with_collage != 0;
     return FIC_OK;
+}
+
+int fic_rgb_ctx_set_option(fic_rgb_ctx* c, const char* name, int value)
+{
+    if (!c || !name) return fail(FIC_E_ARGUMENT, "fic_rgb_ctx_set_option: null argument");
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (!strcmp(name, "sweep")) {
+        if (value < 0 || value > 2) return fail(FIC_E_ARGUMENT, "fic_rgb_ctx_set_option: sweep must be 0 (auto), 1 (VALU) or 2 (matrix cores)");
+        c->opt_sweep = value;
+        return FIC_OK;
+    }
+    return fail(FIC_E_ARGUMENT, "fic_rgb_ctx_set_option: unknown option '%s'", name);
+}
+
+int fic_rgb_ctx_last_sweep(fic_rgb_ctx* c)
+{
+    if (!c) return fail(FIC_E_ARGUMENT, "fic_rgb_ctx_last_sweep: null context");
+    return c->last_sweep;
 }
 
 int fic_rgb_ctx_sync(fic_rgb_ctx* c)

@@ -72,8 +72,16 @@ struct FicRgbBuffers {
     FicRgbRngStat* rng_st;   // [N_r]
     unsigned long long* key; // [N_r]
 };
+// buffers of the matrix-core full search of one image (k_sweep_q<NK, 3>); all NULL = the VALU sweeps
+struct FicRgbQ {
+    void *poolQ = nullptr, *dflat = nullptr, *rngQ = nullptr, *qst = nullptr, *rngE = nullptr, *theta_g = nullptr, *amax = nullptr;
+    int ndtiles = 0, ndtiles_alloc = 0, nct_alloc = 0, tiles_per_chunk = 0, nchunks = 0;
+};
 int fic_launch_rgb_encode(const FicRgbBuffers& b, const FicRgbOutputs& out, int32_t* collage, const FicGeom& g,
-                          hipStream_t s);
+                          hipStream_t s, const FicRgbQ* q = nullptr);
+int fic_launch_rgbq(const uint16_t* pool_sum, const FicRgbDomStat* pool_st, const int16_t* rng_t, const FicRgbRngStat* rng_st,
+                    unsigned long long* key, void* poolQ, void* dflat, void* rngQ, void* qst, void* rngE, void* theta_g, void* amax,
+                    const FicGeom& g, int ndtiles, int ndtiles_alloc, int nct_alloc, int tiles_per_chunk, int nchunks, hipStream_t s);
 
 // opt-in matrix-core sweeps ("sweep" = 3)
 int fic_mfma8_group(int B);          // range blocks per workgroup of the 8-isometry kernel

@@ -338,6 +338,10 @@ struct QArgs {
     const float* rngE;
     unsigned long long* key;
     uint32_t* theta_g;               // [plane][Nr_pad] best published level per range (order-preserving integer image; 0 = none)
+    const int16_t* rgb_rng;          // MODE 3 (joint RGB): greyR_i [N_r][n], R+G+B per pool pixel [N_d][n], pool statistics
+    const uint16_t* rgb_pool;
+    const FicRgbDomStat* rgb_dst;
+    float lmin;                      // L of a pair that prunes regardless of index order: 0.26 x the largest possible `rem`
     unsigned long long* stats;       // optional [8]: tile epilogues, tiles with flagged pairs, queued entries, waves; of every
                                      //   64th wave: shader-clock cycles and 100 MHz ticks it was alive (summed), their number
     int Nd, Nd_pad, Nr, Nr_pad, n, lgn, W, H, Rw;
@@ -375,8 +379,8 @@ __device__ __forceinline__ float max16_sum(const v16f& a, const v16f& b)
 }
 
 template <int MODE> struct QMode {
-    static constexpr int CSHIFT = MODE == 0 ? 0 : (MODE == 1 ? 3 : 2);   // log2(columns per range block)
-    static constexpr int NISO = MODE == 0 ? 1 : 8;
+    static constexpr int CSHIFT = (MODE == 0 || MODE == 3) ? 0 : (MODE == 1 ? 3 : 2);   // log2(columns per range block)
+    static constexpr int NISO = (MODE == 0 || MODE == 3) ? 1 : 8;
 };
 // first isometry of column sub-index c (MODE 2: of the pair {0,2}, {1,3}, {4,5}, {6,7})
 template <int MODE> __device__ __forceinline__ int q_col_iso(int c) { return MODE == 2 ? (c == 0 ? 0 : (c == 1 ? 1 : (c == 2 ? 4 : 6))) : c; }
@@ -402,6 +406,31 @@ __device__ __forceinline__ void q_flush(const QArgs& A, const uint32_t* myq, int
             const uint32_t d = ent & 0x00FFFFFFu;
             if (d >= (uint32_t)A.Nd) continue;                 // a zero row behind the pool, flagged while theta was "none"
             const int col = ctw0 * 32 + (int)(ent >> 24);
+            if constexpr (MODE == 3) {
+                // getErrorVarianceCovarianceRGB FC:781-803: kovarianz accumulated in f32 in the order i = 0..n-1 (the sums exceed
+                // 2^24: the order is part of the result), r in f32, error = varianzRange^2 * (1 - r^2); rst[].rem = varianzRange
+                const FicRngStat rs = rst[col];
+                const FicRgbDomStat ds = A.rgb_dst[d];
+                const uint4* rt = (const uint4*)(A.rgb_rng + (size_t)col * (B * B));
+                const uint4* ps = (const uint4*)(A.rgb_pool + (size_t)d * (B * B));
+                float kov = 0.0f;
+#pragma unroll 4
+                for (int q = 0; q < B * B / 8; q++) {
+                    const uint4 r4 = rt[q], p4 = ps[q];
+                    const uint32_t rw[4] = {r4.x, r4.y, r4.z, r4.w}, pw[4] = {p4.x, p4.y, p4.z, p4.w};
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        kov = __fadd_rn(kov, (float)((int)(int16_t)(rw[u] & 0xffffu) * ((int)(pw[u] & 0xffffu) - ds.msum)));
+                        kov = __fadd_rn(kov, (float)((int)(int16_t)(rw[u] >> 16) * ((int)(pw[u] >> 16) - ds.msum)));
+                    }
+                }
+                const float vRf = (float)rs.rem;
+                float r = (rs.rem == 0 || ds.vD == 0) ? 0.0f : __fdiv_rn(kov, __fmul_rn(vRf, (float)ds.vD));
+                r = __fmul_rn(r, r);
+                const float e = __fmul_rn(__fmul_rn(vRf, vRf), __fsub_rn(1.0f, r));
+                atomicMin(&keyp[col], ((unsigned long long)f32_orderable(e) << 32) | d);
+                continue;
+            }
             const int j = col >> CSHIFT, k = q_col_iso<MODE>(col & ((1 << CSHIFT) - 1));
             const int k2 = k == 0 ? 2 : (k == 1 ? 3 : k + 1);                       // MODE 2: the pair's second isometry
             const FicRngStat rs = rst[j];
@@ -516,7 +545,7 @@ __global__ __launch_bounds__(64 * FIC_Q_WPG, NK == 4 ? FIC_Q_WAVES_B8 : (NK < 4 
     // the prefetched fragment loads as well: s_waitcnt vmcnt(0))
     const uint32_t AS4* pflat = (const uint32_t AS4*)(uintptr_t)(A.dflat + (size_t)plane * A.ndtiles_alloc);
     const v16f zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    const float lmin = 0.26f * (float)A.n;                   // L of a pair that prunes regardless of index order (header)
+    const float lmin = A.lmin;                               // L of a pair that prunes regardless of index order (header)
     int qn = 0;                                              // queued entries (wave-uniform)
     unsigned st_slow = 0, st_pairs = 0;                      // instrumentation (wave-uniform; reported when A.stats is set)
 
@@ -723,6 +752,8 @@ int fic_launch_sweep_q(const FicBuffers& b, const void* poolQ, const void* dflat
     const int CT = fic_q_ct(g.B);
     A.nctg = (ct_end - ct_begin + CT - 1) / CT;
     A.planes = g.planes;
+    A.lmin = 0.26f * (float)g.n;
+    A.rgb_rng = nullptr; A.rgb_pool = nullptr; A.rgb_dst = nullptr;
     // the loop reads up to ndtiles_loop + prefetch distance tiles; chunks must be whole unrolled iterations
     if (ct_begin + A.nctg * CT > nct_alloc || g.Nd >= (1 << 24) || A.ndtiles_loop + unroll > ndtiles_alloc || tiles_per_chunk % unroll)
         return (int)hipErrorInvalidValue;
@@ -734,6 +765,152 @@ int fic_launch_sweep_q(const FicBuffers& b, const void* poolQ, const void* dflat
     else if (g.B == 8 && mode == 2) hipLaunchKernelGGL((k_sweep_q<4, 2>), grid, block, 0, s, A);
     else if (g.B == 16 && mode == 0) hipLaunchKernelGGL((k_sweep_q<16, 0>), grid, block, 0, s, A);
     else if (g.B == 16 && mode == 2) hipLaunchKernelGGL((k_sweep_q<16, 2>), grid, block, 0, s, A);
+    else return (int)hipErrorInvalidValue;
+    FIC_LAUNCH_CHECK();
+    return 0;
+}
+
+// =============================================================================================
+// Joint RGB (encodeRGB FC:171-219) through the same sweep: k_sweep_q<NK, 3>.
+// getErrorVarianceCovarianceRGB (FC:760-808) has the shape of the grey error with other constants: with
+//   greyR_i = sum over the channels of (range pixel - channel mean), greyD_i likewise for the domain block,
+//   kovarianz = sum greyR_i greyD_i,  varianzRange = sum greyR_i (= vR, an integer in [0, 3(n-1)]),  varianzDomain = sum greyD_i (= vD)
+//   r = kovarianz / (vR * vD)  (0 when vR == 0 or vD == 0),   error = vR^2 (1 - r^2)
+// i.e. the grey formulas with rem := vR and q := kovarianz / vD.  So the domain operand is A[d][i] = f16(greyD_i / vD) (zero for
+// vD == 0), the range operand B[i][c] = f16(greyR_i) (integers in [-765, 765]: exact), acc ~ q, and theta / the queue / the
+// any-order rules are those of the grey sweep with lmin = 0.26 * 3n (vR < 3n).  Differences:
+//  * ||A_d|| is not 1: |acc - q| <= 2^-11 * 1.07 * ||greyR|| * ||A_d||, bounded per range with Amax = max_d ||A_d|| (the blocks
+//    that can win have small vD and large norm, so the bound is tight where it matters);
+//  * Java accumulates kovarianz in f32 in the order i = 0..n-1 and the sums exceed 2^24: the value the reference compares is
+//    kov_J with |kov_J - kovarianz| <= n 2^-24 sum|greyR_i greyD_i|, i.e. another 4e-6 * ||greyR|| * Amax on q -- inside the
+//    slack of the 7.0e-4 coefficient (2^-11 * 1.07 = 5.2e-4); the exact evaluation of a flagged pair reproduces that order;
+//  * r is a correctly rounded f32 quotient (FC:800) instead of an f64 quotient cast to f32: still a monotone function of
+//    |kov_J / vD| for a fixed range, which is all the pruning argument of the header needs.
+// Inputs are what k_pool_rgb / k_range_rgb (fic_rgb.hip) already produce: R+G+B per pool pixel, greyR_i, the statistics.
+// =============================================================================================
+__global__ __launch_bounds__(256) void k_pool_qrgb(const uint16_t* __restrict__ pool_sum, const FicRgbDomStat* __restrict__ dst,
+                                                   v4i* __restrict__ poolQ, uint32_t* __restrict__ dflat,
+                                                   uint32_t* __restrict__ amax, FicGeom g)
+{
+    __shared__ uint32_t s_norm;
+    const int n = g.n, NK = n / 16;
+    const int dtile = blockIdx.x;
+    if (threadIdx.x == 0) s_norm = 0u;
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        const int d = dtile * 32 + threadIdx.x;
+        float norm = 0.0f;
+        if (d < g.Nd) {
+            const FicRgbDomStat ds = dst[d];
+            if (ds.vD != 0) {
+                const uint16_t* ps = pool_sum + (size_t)d * n;
+                long long s2 = 0;
+                for (int i = 0; i < n; i++) {
+                    const int gd = (int)ps[i] - ds.msum;
+                    s2 += gd * gd;
+                }
+                // ||A_d|| rounded up: the factor covers sqrt, the division and the f16 rounding of the elements
+                norm = __fmul_rn(__fdiv_rn(__fsqrt_rn((float)s2), (float)ds.vD), 1.001f);
+            }
+        }
+        atomicMax(&s_norm, __float_as_uint(norm));          // non-negative floats order like their bit patterns
+    }
+    for (int t = threadIdx.x; t < NK * 64; t += 256) {
+        const int lane = t & 63, m = t >> 6;
+        const int d = dtile * 32 + (lane & 31), h = lane >> 5;
+        v4i v = {0, 0, 0, 0};
+        if (d < g.Nd) {
+            const FicRgbDomStat ds = dst[d];
+            if (ds.vD != 0) {
+                const uint16_t* p = pool_sum + (size_t)d * n + 16 * m + 8 * h;
+                const float vd = (float)ds.vD;
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+                    v[u] = f16_pair(__fdiv_rn((float)((int)p[2 * u] - ds.msum), vd), __fdiv_rn((float)((int)p[2 * u + 1] - ds.msum), vd));
+            }
+        }
+        poolQ[(size_t)dtile * NK * 64 + t] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        dflat[dtile] = s_norm ? 0u : 1u;
+        if (s_norm) atomicMax(amax, s_norm);
+    }
+}
+
+// one workgroup per 64 range blocks (= 2 column tiles): B fragments, rem := varianzRange, E_r, key / theta reset
+__global__ __launch_bounds__(256) void k_range_qrgb(const int16_t* __restrict__ rng_t, const FicRgbRngStat* __restrict__ rst,
+                                                    FicRngStat* __restrict__ qst, float* __restrict__ rngE,
+                                                    unsigned long long* __restrict__ key, uint32_t* __restrict__ theta_g,
+                                                    v4i* __restrict__ rngQ, const uint32_t* __restrict__ amax, FicGeom g,
+                                                    int nct_alloc)
+{
+    const int n = g.n, NK = n / 16;
+    const int j0 = blockIdx.x * 64;
+    if (threadIdx.x < 64) {
+        const int j = j0 + threadIdx.x;
+        if (j < g.Nr) {
+            const int16_t* rt = rng_t + (size_t)j * n;
+            long long s2 = 0;
+            for (int i = 0; i < n; i++) s2 += (int)rt[i] * (int)rt[i];
+            const float am = __uint_as_float(*amax);
+            FicRngStat st;
+            st.rM = 0;
+            st.rem = rst[j].vR;
+            qst[j] = st;
+            rngE[j] = __fadd_rn(__fmul_rn(__fmul_rn(__fmul_rn(__fsqrt_rn((float)s2), 1.0001f), am), FIC_Q_ECOEF),
+                                __fmul_rn(FIC_Q_EABS, __fadd_rn(1.0f, am)));
+            key[j] = FIC_KEY_NONE;
+            theta_g[j] = 0u;
+        }
+    }
+    for (int t = threadIdx.x; t < 2 * NK * 64; t += 256) {
+        const int lane = t & 63, m = (t >> 6) % NK, ctl = (t >> 6) / NK;
+        const int j = j0 + ctl * 32 + (lane & 31), h = lane >> 5;
+        v4i v = {0, 0, 0, 0};
+        if (j < g.Nr) {
+            const int16_t* p = rng_t + (size_t)j * n + 16 * m + 8 * h;
+#pragma unroll
+            for (int u = 0; u < 4; u++) v[u] = f16_pair((float)p[2 * u], (float)p[2 * u + 1]);
+        }
+        const int ct = j0 / 32 + ctl;
+        if (ct < nct_alloc) rngQ[((size_t)ct * NK + m) * 64 + lane] = v;
+    }
+}
+
+// prep + sweep of one RGB image (planes = 1 geometry); q buffers as in QArgs, sized by the caller (fic_capi_rgb.cpp)
+int fic_launch_rgbq(const uint16_t* pool_sum, const FicRgbDomStat* pool_st, const int16_t* rng_t, const FicRgbRngStat* rng_st,
+                    unsigned long long* key, void* poolQ, void* dflat, void* rngQ, void* qst, void* rngE, void* theta_g, void* amax,
+                    const FicGeom& g, int ndtiles, int ndtiles_alloc, int nct_alloc, int tiles_per_chunk, int nchunks, hipStream_t s)
+{
+    if (hipMemsetAsync(amax, 0, sizeof(uint32_t), s) != hipSuccess) return (int)hipErrorUnknown;
+    hipLaunchKernelGGL(k_pool_qrgb, dim3(ndtiles_alloc), dim3(256), 0, s, pool_sum, pool_st, (v4i*)poolQ, (uint32_t*)dflat,
+                       (uint32_t*)amax, g);
+    FIC_LAUNCH_CHECK();
+    const int CT = fic_q_ct(g.B);
+    const int nct = (g.Nr + 31) / 32;
+    hipLaunchKernelGGL(k_range_qrgb, dim3(nct_alloc / 2), dim3(256), 0, s, rng_t, rng_st, (FicRngStat*)qst, (float*)rngE, key,
+                       (uint32_t*)theta_g, (v4i*)rngQ, (const uint32_t*)amax, g, nct_alloc);
+    FIC_LAUNCH_CHECK();
+    QArgs A;
+    A.stats = nullptr;
+    A.poolQ = (const v4i*)poolQ; A.dflat = (const uint32_t*)dflat; A.pool_pix = nullptr; A.pool_st = nullptr; A.pool_s64 = nullptr;
+    A.rngQ = (const v4i*)rngQ; A.rngC = nullptr; A.rng_st = (const FicRngStat*)qst; A.rngE = (const float*)rngE; A.key = key;
+    A.theta_g = (uint32_t*)theta_g;
+    A.rgb_rng = rng_t; A.rgb_pool = pool_sum; A.rgb_dst = pool_st;
+    A.lmin = 0.26f * 3.0f * (float)g.n;
+    A.Nd = g.Nd; A.Nd_pad = g.Nd; A.Nr = g.Nr; A.Nr_pad = g.Nr; A.n = g.n; A.lgn = g.lgn; A.W = g.W; A.H = g.H; A.Rw = g.Rw;
+    const int unroll = FIC_Q_UNROLL;
+    A.ndtiles = ndtiles; A.ndtiles_loop = (ndtiles + unroll - 1) / unroll * unroll; A.ndtiles_alloc = ndtiles_alloc; A.nct_alloc = nct_alloc;
+    A.ct_begin = 0; A.ct_end = nct; A.tiles_per_chunk = tiles_per_chunk; A.nchunks = nchunks;
+    A.nctg = (nct + CT - 1) / CT;
+    A.planes = 1;
+    if (A.nctg * CT > nct_alloc || (nct_alloc & 1) || g.Nd >= (1 << 24) || A.ndtiles_loop + unroll > ndtiles_alloc || tiles_per_chunk % unroll)
+        return (int)hipErrorInvalidValue;
+    dim3 grid((unsigned)nchunks * (unsigned)A.nctg), block(64 * FIC_Q_WPG);
+    if (g.B == 4) hipLaunchKernelGGL((k_sweep_q<1, 3>), grid, block, 0, s, A);
+    else if (g.B == 8) hipLaunchKernelGGL((k_sweep_q<4, 3>), grid, block, 0, s, A);
+    else if (g.B == 16) hipLaunchKernelGGL((k_sweep_q<16, 3>), grid, block, 0, s, A);
     else return (int)hipErrorInvalidValue;
     FIC_LAUNCH_CHECK();
     return 0;

@@ -300,7 +300,7 @@ __global__ __launch_bounds__(256) void k_decode_paint_rgb(const int32_t* __restr
 // host-side launchers
 // joint-RGB encode, single image: scale, pool, ranges, sweep, finalise (+ collage when asked)
 int fic_launch_rgb_encode(const FicRgbBuffers& b, const FicRgbOutputs& out, int32_t* collage, const FicGeom& g,
-                          hipStream_t s)
+                          hipStream_t s, const FicRgbQ* q)
 {
     hipLaunchKernelGGL(k_scale_rgb, dim3((g.Ws + 255) / 256, g.Hs), dim3(256), 0, s, (const int32_t*)b.argb, b.scaled, g);
     FIC_LAUNCH_CHECK();
@@ -309,7 +309,13 @@ int fic_launch_rgb_encode(const FicRgbBuffers& b, const FicRgbOutputs& out, int3
     FIC_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_range_rgb, dim3((g.Nr + 255) / 256), dim3(256), 0, s, (const int32_t*)b.argb, b.rng_t, b.rng_st, g);
     FIC_LAUNCH_CHECK();
-    if (g.full && g.B <= 8 && b.pool_cf) {
+    if (g.full && q && q->poolQ) {
+        // full search on the matrix cores (fic_q.hip, k_sweep_q<NK, 3>): the MFMA output prunes, flagged pairs are evaluated
+        // with the reference's sequential f32 sums
+        if (fic_launch_rgbq(b.pool_sum, b.pool_st, b.rng_t, b.rng_st, b.key, q->poolQ, q->dflat, q->rngQ, q->qst, q->rngE, q->theta_g,
+                            q->amax, g, q->ndtiles, q->ndtiles_alloc, q->nct_alloc, q->tiles_per_chunk, q->nchunks, s))
+            return (int)hipErrorUnknown;
+    } else if (g.full && g.B <= 8 && b.pool_cf) {
         // full search: lane = range block, wave-uniform domain blocks, pool chunks across workgroups
         const size_t total = (size_t)g.Nd * g.n;
         hipLaunchKernelGGL(k_pool_rgb_centred, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s,

@@ -59,3 +59,32 @@ for W, planes, wK in ((256, 16, 2), (256, 16, None), (512, 8, 16), (512, 8, None
     ctx[f"{planes}x{W}x{W}_B{B}_wK{wk}{'_full' if wK is None else ''}"] = {"ms_per_batch": dt * 1e3, "ms_per_image": dt * 1e3 / planes,
                                                                              "matches_per_s": nr / dt}
 print(json.dumps({"rgb_contexts_device_resident": ctx}, indent=1))
+
+# full search: the VALU sweep ("sweep" = 1) beside the matrix-core sweep ("sweep" = 2, the default from 3e7 pairs), device-resident input
+cmp = {}
+for W, B in ((512, 8), (1024, 8), (1024, 4), (2048, 8), (2048, 16), (4096, 8)):
+    Dw = fic_amd.geometry(W, W, B)[2]
+    r, g, b = (fic_amd.synth.image_u(W, W, 0xC0300 + c).astype(np.int64) for c in range(3))
+    t = torch.from_numpy(((np.int64(255) << 24) | (r << 16) | (g << 8) | b).astype(np.uint32).view(np.int32).reshape(1, -1)).cuda()
+    row = {}
+    for sweep in (1, 2):
+        if sweep == 1 and (W >= 4096 or (B == 16 and W >= 2048)):
+            continue                        # seconds per encode on the VALU path (B = 16: the window kernel)
+        with capi.RgbEncoder(W, W, B, Dw, 1) as enc:
+            enc.set_option("sweep", sweep)
+            enc.set_argb(t)
+            s = torch.cuda.current_stream()
+            enc.encode(False, s)
+            enc.sync()
+            reps = 2 if W >= 2048 else 5
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                enc.encode(False, s)
+            enc.sync()
+            dt = (time.perf_counter() - t0) / reps
+        nr, nd = (W // B) ** 2, Dw * Dw
+        row["valu" if sweep == 1 else "matrix_core"] = {"ms_per_image": dt * 1e3, "matches_per_s": nr / dt, "pair_evals_per_s": nr * nd / dt}
+    if "valu" in row:
+        row["speedup"] = row["valu"]["ms_per_image"] / row["matrix_core"]["ms_per_image"]
+    cmp[f"{W}x{W}_B{B}_full"] = row
+print(json.dumps({"rgb_full_search_valu_vs_matrix_core": cmp}, indent=1))
