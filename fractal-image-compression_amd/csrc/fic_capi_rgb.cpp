@@ -130,7 +130,6 @@ fic_rgb_ctx* fic_rgb_ctx_create(int device, int w, int h, int B, int wK, int pla
     auto A = [&](int r) { if (rc == FIC_OK) rc = r; };
     A(dev_alloc(&c->scaled, P * g.Ws * g.Hs));
     A(dev_alloc(&c->pool_sum, P * nd * n));
-    if (g.full && g.B <= 8) A(dev_alloc(&c->pool_cf, P * nd * n));      // fast full-search sweep (k_sweep_rgb_fast)
     A(dev_alloc(&c->pool_st, P * nd));
     A(dev_alloc(&c->rng_t, P * nr * n));
     A(dev_alloc(&c->rng_st, P * nr));
@@ -201,6 +200,10 @@ int fic_rgb_ctx_encode(fic_rgb_ctx* c, int with_collage, void* hip_stream)
         if (env[0] >= '1' && env[0] <= '2' && !env[1]) want = env[0] - '0';
     const bool use_q = g.full && (want == 2 || (want == 0 && ((double)g.Nr * g.Nd >= 3e7 || g.B == 16)));
     if (use_q && rgb_q_setup(c)) return FIC_E_HIP;
+    if (!use_q && g.full && g.B <= 8 && !c->pool_cf) {      // the VALU full-search sweep's f32 pool copy (k_sweep_rgb_fast), on first use
+        const int rc = dev_alloc(&c->pool_cf, (size_t)g.planes * g.Nd * g.n);
+        if (rc != FIC_OK) return rc;
+    }
     c->last_sweep = use_q ? 2 : 1;
     for (int p = 0; p < g.planes; p++) {
         FicRgbBuffers b;

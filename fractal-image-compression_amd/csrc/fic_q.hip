@@ -485,9 +485,9 @@ __device__ __forceinline__ float q_share_max(float v)
     return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
 }
 
-// Launch bounds: asking for two waves per SIMD at B = 4 / 8 caps the kernel at the 256 architectural VGPRs, and only then does
-// the compiler emit the MFMAs with VGPR destinations; without the cap every accumulator lands in an AGPR and each element
-// the epilogue tests costs a v_accvgpr_read first (16-32 extra VALU issues per tile: more than the epilogue itself).
+// Launch bounds: the register budget is cut for FIC_Q_WAVES_* waves per SIMD (<= 256 VGPRs at B = 4 / 8), which also makes the
+// compiler emit the MFMAs with VGPR destinations whatever the build flags say (the library is built with -mllvm
+// -amdgpu-mfma-vgpr-form; with accumulators in AGPRs every element the epilogue tests costs a v_accvgpr_read first).
 template <int NK, int MODE>
 __global__ __launch_bounds__(64 * FIC_Q_WPG, NK == 4 ? FIC_Q_WAVES_B8 : (NK < 4 ? FIC_Q_WAVES_B4 : 1)) void k_sweep_q(QArgs A)
 {
