@@ -72,6 +72,25 @@ def test_lena_colored_and_extreme_images(oracle, lena_colored):
             _same(_encode([argb], 64, 64, B, 2), _oracle_dict(oracle, argb, 64, 64, B), 0)
 
 
+@pytest.mark.parametrize("seed", range(6))
+def test_low_depth_colour_images_with_exact_ties(oracle, seed):
+    """1- and 2-bit channels, blocky structure: many candidates share the best error EXACTLY (the strict '<' of FC:707 keeps
+    the lowest index), varianzDomain and varianzRange hit 0 often, kovarianz sums cancel -- the any-order rules of the
+    prune (seeding from a later pair, theta published across pool chunks) must never drop the earlier of two equal pairs."""
+    rng = np.random.default_rng(1234 + seed)
+    size, B = (64, 4) if seed % 2 == 0 else (128, 8)
+    bits = 1 + seed % 2
+    cell = (2, 4, 8)[seed % 3]
+    low = rng.integers(0, 1 << bits, (size // cell, size // cell, 3), dtype=np.uint8)
+    rgb = np.repeat(np.repeat(low, cell, 0), cell, 1) * (255 // ((1 << bits) - 1))
+    if seed >= 3:                                                  # a few isolated pixels break the block symmetry
+        ys, xs = rng.integers(0, size, 40), rng.integers(0, size, 40)
+        rgb[ys, xs] = rng.integers(0, 256, (40, 3), dtype=np.uint8)
+    argb = oracle.rgb_to_argb(np.ascontiguousarray(rgb.astype(np.uint8)))
+    _same(_encode([argb], size, size, B, 2), _oracle_dict(oracle, argb, size, size, B), 0)
+    _same(_encode([argb], size, size, B, 1), _oracle_dict(oracle, argb, size, size, B), 0)
+
+
 @pytest.mark.parametrize("size,B,flat", [(512, 8, False), (512, 8, True), (512, 4, False), (1024, 16, False), (768, 8, True)])
 def test_matrix_core_equals_valu_sweep_on_large_images(oracle, size, B, flat):
     """Sizes the scalar oracle does not finish in seconds: the two GPU sweeps (different arithmetic paths to the same
