@@ -30,6 +30,7 @@ struct fic_rgb_ctx {
     uint32_t* dec_sq = nullptr;
     FicRgbQ q;                       // matrix-core full search (allocated on first use; one image at a time, stream-ordered)
     int opt_sweep = 0;               // 0 auto, 1 VALU sweeps, 2 matrix-core full search
+    int opt_chunks = 0;              // pool chunks of the matrix-core sweep (0 = automatic)
     int last_sweep = 0;              // what the last encode ran: 1 / 2
     bool have_input = false, encoded_any = false, have_collage = false;
     hipStream_t last_stream = nullptr;
@@ -67,7 +68,32 @@ void rgb_plane(const fic_rgb_ctx* c, int p, FicRgbBuffers* b, FicRgbOutputs* o)
     o->bB = c->bB + P * nr;
     o->qrows = c->qrows + P * nr * 5;
 }
-// buffers and chunking of the matrix-core full search (same shapes and chunk policy as the grey q sweep)
+// pool chunks of the matrix-core full search: the policy of the grey q sweep (fic_capi.cpp, q_sweep), or the "chunks" option
+void rgb_q_chunks(fic_rgb_ctx* c)
+{
+    const FicGeom& g = c->g;
+    FicRgbQ& q = c->q;
+    const int unroll = fic_q_unroll(g.B, 1), CT = fic_q_ct(g.B);
+    const int nct = (g.Nr + 31) / 32;
+    long long nc = c->opt_chunks;
+    if (nc <= 0) {
+        const long long base_wg = (nct + CT - 1) / CT;
+        const long long resident = 256LL * fic_q_resident(g.B);
+        auto ceil_div = [](long long a, long long b) { return (a + b - 1) / b; };
+        long long fill = base_wg < resident ? ceil_div(2 * resident, base_wg) : 1;
+        if (fill > q.ndtiles / 16) fill = q.ndtiles / 16;
+        long long bal = ceil_div(8 * resident, base_wg);
+        if (bal > q.ndtiles / 1024) bal = q.ndtiles / 1024;
+        nc = fill > bal ? fill : bal;
+    }
+    if (nc < 1) nc = 1;
+    if (nc > q.ndtiles) nc = q.ndtiles;
+    int tpc = (int)((q.ndtiles + nc - 1) / nc);
+    tpc = (tpc + unroll - 1) / unroll * unroll;
+    q.tiles_per_chunk = tpc;
+    q.nchunks = (q.ndtiles + tpc - 1) / tpc;
+}
+// buffers of the matrix-core full search (same shapes as the grey q sweep)
 int rgb_q_setup(fic_rgb_ctx* c)
 {
     const FicGeom& g = c->g;
@@ -79,19 +105,6 @@ int rgb_q_setup(fic_rgb_ctx* c)
     q.ndtiles_alloc = q.ndtiles + 2 * unroll;
     const int nct = (g.Nr + 31) / 32;
     q.nct_alloc = ((nct + CT - 1) / CT * CT + CT + 1) & ~1;
-    const long long base_wg = (nct + CT - 1) / CT;
-    const long long resident = 256LL * fic_q_resident(g.B);
-    auto ceil_div = [](long long a, long long b) { return (a + b - 1) / b; };
-    long long fill = base_wg < resident ? ceil_div(2 * resident, base_wg) : 1;
-    if (fill > q.ndtiles / 16) fill = q.ndtiles / 16;
-    long long bal = ceil_div(8 * resident, base_wg);
-    if (bal > q.ndtiles / 1024) bal = q.ndtiles / 1024;
-    long long nc = fill > bal ? fill : bal;
-    if (nc < 1) nc = 1;
-    int tpc = (int)((q.ndtiles + nc - 1) / nc);
-    tpc = (tpc + unroll - 1) / unroll * unroll;
-    q.tiles_per_chunk = tpc;
-    q.nchunks = (q.ndtiles + tpc - 1) / tpc;
     int rc = FIC_OK;
     auto A = [&](hipError_t e) { if (rc == FIC_OK && e != hipSuccess) rc = fail(FIC_E_HIP, "RGB matrix-core buffers: %s", hipGetErrorString(e)); };
     A(hipMalloc(&q.poolQ, (size_t)q.ndtiles_alloc * NK * 64 * 16));
@@ -200,6 +213,7 @@ int fic_rgb_ctx_encode(fic_rgb_ctx* c, int with_collage, void* hip_stream)
         if (env[0] >= '1' && env[0] <= '2' && !env[1]) want = env[0] - '0';
     const bool use_q = g.full && (want == 2 || (want == 0 && ((double)g.Nr * g.Nd >= 3e7 || g.B == 16)));
     if (use_q && rgb_q_setup(c)) return FIC_E_HIP;
+    if (use_q) rgb_q_chunks(c);
     if (!use_q && g.full && g.B <= 8 && !c->pool_cf) {      // the VALU full-search sweep's f32 pool copy (k_sweep_rgb_fast), on first use
         const int rc = dev_alloc(&c->pool_cf, (size_t)g.planes * g.Nd * g.n);
         if (rc != FIC_OK) return rc;
@@ -224,6 +238,11 @@ int fic_rgb_ctx_set_option(fic_rgb_ctx* c, const char* name, int value)
     if (!strcmp(name, "sweep")) {
         if (value < 0 || value > 2) return fail(FIC_E_ARGUMENT, "fic_rgb_ctx_set_option: sweep must be 0 (auto), 1 (VALU) or 2 (matrix cores)");
         c->opt_sweep = value;
+        return FIC_OK;
+    }
+    if (!strcmp(name, "chunks")) {
+        if (value < 0) return fail(FIC_E_ARGUMENT, "fic_rgb_ctx_set_option: chunks must be >= 0");
+        c->opt_chunks = value;
         return FIC_OK;
     }
     return fail(FIC_E_ARGUMENT, "fic_rgb_ctx_set_option: unknown option '%s'", name);

@@ -164,7 +164,8 @@ FIC_API int fic_rgb_ctx_encode(fic_rgb_ctx* ctx, int with_collage, void* hip_str
 FIC_API int fic_rgb_ctx_sync(fic_rgb_ctx* ctx);
 /* "sweep": 0 (default) = automatic, 1 = the VALU sweeps, 2 = the matrix-core full search (k_sweep_q<NK, 3>: prune on the
  * MFMA output, flagged pairs with the reference's sequential f32 sums; full search only).  All choices give the same
- * bits.  The environment variable FIC_RGB_SWEEP=1|2 overrides.  fic_rgb_ctx_last_sweep: what the last encode ran (1 / 2). */
+ * bits.  The environment variable FIC_RGB_SWEEP=1|2 overrides.  fic_rgb_ctx_last_sweep: what the last encode ran (1 / 2).
+ * "chunks": pool chunks of the matrix-core sweep (0 = automatic; results do not depend on it). */
 FIC_API int fic_rgb_ctx_set_option(fic_rgb_ctx* ctx, const char* name, int value);
 FIC_API int fic_rgb_ctx_last_sweep(fic_rgb_ctx* ctx);
 FIC_API int fic_rgb_ctx_get_results_host(fic_rgb_ctx* ctx, int32_t* idx_local, float* a, float* bR, float* bG, float* bB,

@@ -15,10 +15,11 @@ def _rgb_synth(w, h, seed, flat=False):
     return np.stack([f(w, h, seed), f(w, h, seed + 1), f(w, h, seed + 2)], axis=-1)
 
 
-def _encode(argbs, w, h, B, sweep):
+def _encode(argbs, w, h, B, sweep, chunks=0):
     Dw = fic_amd.geometry(w, h, B)[2]
     with fic_amd.capi.RgbEncoder(w, h, B, Dw, planes=len(argbs)) as enc:
         enc.set_option("sweep", sweep)
+        enc.set_option("chunks", chunks)
         enc.set_argb(np.stack(argbs))
         enc.encode(with_collage=False)
         r = enc.results()
@@ -49,8 +50,10 @@ def test_matrix_core_full_search_matches_the_oracle(oracle, size, B, flat):
     of 32 (200x200), all three block sizes (B = 16 has no VALU full-search kernel: it was the window kernel before)."""
     rgb = _rgb_synth(size, size, 900 + B + size, flat)
     argb = oracle.rgb_to_argb(rgb)
-    got = _encode([argb], size, size, B, 2)
-    _same(got, _oracle_dict(oracle, argb, size, size, B), 0)
+    ref = _oracle_dict(oracle, argb, size, size, B)
+    _same(_encode([argb], size, size, B, 2), ref, 0)
+    for chunks in (3, 40, 100000):          # up to one chunk per domain tile: every tile seeds theta out of order, theta_g is shared
+        _same(_encode([argb], size, size, B, 2, chunks), ref, 0)
 
 
 def test_lena_colored_and_extreme_images(oracle, lena_colored):
@@ -87,8 +90,10 @@ def test_low_depth_colour_images_with_exact_ties(oracle, seed):
         ys, xs = rng.integers(0, size, 40), rng.integers(0, size, 40)
         rgb[ys, xs] = rng.integers(0, 256, (40, 3), dtype=np.uint8)
     argb = oracle.rgb_to_argb(np.ascontiguousarray(rgb.astype(np.uint8)))
-    _same(_encode([argb], size, size, B, 2), _oracle_dict(oracle, argb, size, size, B), 0)
-    _same(_encode([argb], size, size, B, 1), _oracle_dict(oracle, argb, size, size, B), 0)
+    ref = _oracle_dict(oracle, argb, size, size, B)
+    for chunks in (0, 5, 100000):
+        _same(_encode([argb], size, size, B, 2, chunks), ref, 0)
+    _same(_encode([argb], size, size, B, 1), ref, 0)
 
 
 @pytest.mark.parametrize("size,B,flat", [(512, 8, False), (512, 8, True), (512, 4, False), (1024, 16, False), (768, 8, True)])
