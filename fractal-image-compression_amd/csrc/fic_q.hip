@@ -164,19 +164,25 @@ __global__ __launch_bounds__(256) void k_pool_q(const uint8_t* __restrict__ scal
         const float w = s_w[i];
         const int dM = s_mean[i];
         v4i v;
+        // (8 consecutive pixels = one 8-byte LDS read; rows of pix are 272 bytes apart, positions are multiples of 8)
         if (!folded) {
-            const uint8_t* p = &pix[i][16 * m + 8 * h];
+            const uint2 pw = *(const uint2*)&pix[i][16 * m + 8 * h];
+            int px[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) px[u] = (int)(((u < 4 ? pw.x : pw.y) >> (8 * (u & 3))) & 0xffu);
 #pragma unroll
             for (int u = 0; u < 4; u++)
-                v[u] = f16_pair(__fmul_rn((float)((int)p[2 * u] - dM), w), __fmul_rn((float)((int)p[2 * u + 1] - dM), w));
+                v[u] = f16_pair(__fmul_rn((float)(px[2 * u] - dM), w), __fmul_rn((float)(px[2 * u + 1] - dM), w));
         } else {
             // steps m < NK/2: even part (x + x')/2 of positions [16m + 8h, +8), x' at n-1-pos; steps m >= NK/2: odd part (x - x')/2
             const bool odd = m >= NK / 2;
             const int p0 = 16 * (odd ? m - NK / 2 : m) + 8 * h;
+            const uint2 pw = *(const uint2*)&pix[i][p0], qw = *(const uint2*)&pix[i][n - 8 - p0];   // qw: positions n-8-p0 .. n-1-p0
             float f[8];
 #pragma unroll
             for (int u = 0; u < 8; u++) {
-                const int a = pix[i][p0 + u], b = pix[i][n - 1 - (p0 + u)];
+                const int a = (int)(((u < 4 ? pw.x : pw.y) >> (8 * (u & 3))) & 0xffu);
+                const int b = (int)(((u < 4 ? qw.y : qw.x) >> (8 * (3 - (u & 3)))) & 0xffu);           // position n-1-(p0+u)
                 f[u] = __fmul_rn(__fmul_rn((float)(odd ? a - b : a + b - 2 * dM), w), 0.5f);
             }
 #pragma unroll
@@ -202,9 +208,11 @@ __global__ __launch_bounds__(256) void k_pool_q(const uint8_t* __restrict__ scal
 __global__ __launch_bounds__(256) void k_range_q(const uint8_t* __restrict__ gray, FicRngStat* __restrict__ rng_st,
                                                  float* __restrict__ rngE, unsigned long long* __restrict__ key,
                                                  uint32_t* __restrict__ theta_g, v4i* __restrict__ rngQ,
-                                                 uint32_t* __restrict__ rngC, FicGeom g, int nct_alloc, int grp0, int mode)
+                                                 uint32_t* __restrict__ rngC, FicGeom g, int nct_alloc, int grp0, int mode,
+                                                 int staged)
 {
     __shared__ __attribute__((aligned(16))) uint8_t blk[64 * (256 + 4)];
+    extern __shared__ __attribute__((aligned(16))) uint8_t cpy[];   // staged: [columns][n + 8] the copies as bytes
     __shared__ int s_rM[64];
     const int plane = blockIdx.y;
     const int grp = grp0 + blockIdx.x;
@@ -255,54 +263,22 @@ __global__ __launch_bounds__(256) void k_range_q(const uint8_t* __restrict__ gra
         }
     }
     __syncthreads();
-    // fragments: thread = (column tile, m, lane); the copy is gathered through the affine form of iso_source
     const int cpr = mode == 0 ? 1 : (mode == 1 ? 8 : 4);       // columns per range block
     const int lgc = mode == 0 ? 0 : (mode == 1 ? 3 : 2);
     const int cols = 64 * cpr;                                 // columns of this workgroup
     const int ct0 = (j0 * cpr) / 32;
-    for (int t = threadIdx.x; t < (cols / 32) * NK * 64; t += 256) {
-        const int lane = t & 63, m = (t >> 6) % NK, ctl = (t >> 6) / NK;
-        const int col = ctl * 32 + (lane & 31), h = lane >> 5;
-        const int l = col >> lgc, c = col & (cpr - 1);
-        const int k = mode == 2 ? (c == 0 ? 0 : (c == 1 ? 1 : (c == 2 ? 4 : 6))) : c;   // folded: the pair's first isometry
-        int ax, bx, cx, ay, by, cy;
-        iso_affine(iso_inverse(k), B - 1, ax, bx, cx, ay, by, cy);
-        const int s0 = cx + cy * B, sx = ax + ay * B, sy = bx + by * B;                 // source index = s0 + sx*x + sy*y
-        const uint8_t* b = blk + l * stride;
-        const int rM = s_rM[l];
-        const bool real = j0 + l < g.Nr;
-        int a[8];
-        if (mode != 2) {
-            const int p0 = 16 * m + 8 * h;
-#pragma unroll
-            for (int u = 0; u < 8; u++) {
-                const int p = p0 + u;
-                a[u] = (int)b[s0 + sx * (p & (B - 1)) + sy * (p >> lgB)] - rM;
-            }
-        } else {
-            const bool odd = m >= NK / 2;
-            const int q0 = 16 * (odd ? m - NK / 2 : m) + 8 * h;
-#pragma unroll
-            for (int u = 0; u < 8; u++) {
-                const int p = q0 + u, pr = n - 1 - p;
-                const int c0 = b[s0 + sx * (p & (B - 1)) + sy * (p >> lgB)], c1 = b[s0 + sx * (pr & (B - 1)) + sy * (pr >> lgB)];
-                a[u] = odd ? c0 - c1 : c0 + c1 - 2 * rM;
-            }
-        }
-        v4i v;
-#pragma unroll
-        for (int u = 0; u < 4; u++) v[u] = real ? f16_pair((float)a[2 * u], (float)a[2 * u + 1]) : 0;
-        if (ct0 + ctl < nct_alloc) rngQ[((size_t)plane * nct_alloc + ct0 + ctl) * NK * 64 + (size_t)m * 64 + lane] = v;
-    }
-    // the same copies as bytes, n per column, for the exact evaluation of the flagged pairs (q_flush): rngC[plane][column][n]
+    // The columns' isometry copies as bytes, gathered ONCE through the affine form of iso_source: to global memory (rngC, the
+    // operand of the exact evaluation of flagged pairs, q_flush) and -- when they fit (`staged`) -- to LDS, from where the
+    // fragments below read 8 consecutive bytes instead of gathering every pixel a second time.
+    const int cstride = n + 8;
     for (int t = threadIdx.x; t < cols * DW; t += 256) {
         const int col = t / DW, wd = t % DW;
         const int l = col >> lgc, c = col & (cpr - 1);
         if (j0 + l >= g.Nr_pad) break;
-        const int k = mode == 2 ? (c == 0 ? 0 : (c == 1 ? 1 : (c == 2 ? 4 : 6))) : c;
+        const int k = mode == 2 ? (c == 0 ? 0 : (c == 1 ? 1 : (c == 2 ? 4 : 6))) : c;   // folded: the pair's first isometry
         int ax, bx, cx, ay, by, cy;
         iso_affine(iso_inverse(k), B - 1, ax, bx, cx, ay, by, cy);
-        const int s0 = cx + cy * B, sx = ax + ay * B, sy = bx + by * B;
+        const int s0 = cx + cy * B, sx = ax + ay * B, sy = bx + by * B;                 // source index = s0 + sx*x + sy*y
         const uint8_t* b = blk + l * stride;
         uint32_t w = 0;
 #pragma unroll
@@ -311,6 +287,62 @@ __global__ __launch_bounds__(256) void k_range_q(const uint8_t* __restrict__ gra
             w |= (uint32_t)b[s0 + sx * (p & (B - 1)) + sy * (p >> lgB)] << (8 * u);
         }
         rngC[((size_t)plane * g.Nr_pad * cpr + (size_t)j0 * cpr + col) * DW + wd] = w;
+        if (staged) *(uint32_t*)(cpy + col * cstride + 4 * wd) = w;
+    }
+    if (staged) __syncthreads();
+    // fragments: thread = (column tile, m, lane)
+    for (int t = threadIdx.x; t < (cols / 32) * NK * 64; t += 256) {
+        const int lane = t & 63, m = (t >> 6) % NK, ctl = (t >> 6) / NK;
+        const int col = ctl * 32 + (lane & 31), h = lane >> 5;
+        const int l = col >> lgc, c = col & (cpr - 1);
+        const int rM = s_rM[l];
+        const bool real = j0 + l < g.Nr;
+        int a[8];
+        if (staged) {
+            const uint8_t* cp = cpy + col * cstride;
+            if (mode != 2) {
+                const uint2 w = *(const uint2*)(cp + 16 * m + 8 * h);
+#pragma unroll
+                for (int u = 0; u < 8; u++) a[u] = (int)(((u < 4 ? w.x : w.y) >> (8 * (u & 3))) & 0xffu) - rM;
+            } else {
+                const bool odd = m >= NK / 2;
+                const int q0 = 16 * (odd ? m - NK / 2 : m) + 8 * h;
+                const uint2 w = *(const uint2*)(cp + q0), v = *(const uint2*)(cp + n - 8 - q0);   // v: positions n-8-q0 .. n-1-q0
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const int c0 = (int)(((u < 4 ? w.x : w.y) >> (8 * (u & 3))) & 0xffu);
+                    const int c1 = (int)(((u < 4 ? v.y : v.x) >> (8 * (3 - (u & 3)))) & 0xffu);    // position n-1-(q0+u)
+                    a[u] = odd ? c0 - c1 : c0 + c1 - 2 * rM;
+                }
+            }
+        } else {
+            const int k = mode == 2 ? (c == 0 ? 0 : (c == 1 ? 1 : (c == 2 ? 4 : 6))) : c;
+            int ax, bx, cx, ay, by, cy;
+            iso_affine(iso_inverse(k), B - 1, ax, bx, cx, ay, by, cy);
+            const int s0 = cx + cy * B, sx = ax + ay * B, sy = bx + by * B;
+            const uint8_t* b = blk + l * stride;
+            if (mode != 2) {
+                const int p0 = 16 * m + 8 * h;
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const int p = p0 + u;
+                    a[u] = (int)b[s0 + sx * (p & (B - 1)) + sy * (p >> lgB)] - rM;
+                }
+            } else {
+                const bool odd = m >= NK / 2;
+                const int q0 = 16 * (odd ? m - NK / 2 : m) + 8 * h;
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const int p = q0 + u, pr = n - 1 - p;
+                    const int c0 = b[s0 + sx * (p & (B - 1)) + sy * (p >> lgB)], c1 = b[s0 + sx * (pr & (B - 1)) + sy * (pr >> lgB)];
+                    a[u] = odd ? c0 - c1 : c0 + c1 - 2 * rM;
+                }
+            }
+        }
+        v4i v;
+#pragma unroll
+        for (int u = 0; u < 4; u++) v[u] = real ? f16_pair((float)a[2 * u], (float)a[2 * u + 1]) : 0;
+        if (ct0 + ctl < nct_alloc) rngQ[((size_t)plane * nct_alloc + ct0 + ctl) * NK * 64 + (size_t)m * 64 + lane] = v;
     }
 }
 
@@ -730,8 +762,11 @@ int fic_launch_q_prep(const FicBuffers& b, void* poolQ, void* dflat, void* rngQ,
     hipLaunchKernelGGL(k_pool_q, dim3(ndtiles_alloc, g.planes), dim3(256), 0, s, (const uint8_t*)b.scaled, b.pool_pix,
                        b.pool_st, b.pool_var, b.pool_s64, (v4i*)poolQ, (uint32_t*)dflat, g, ndtiles_alloc, mode == 2 ? 1 : 0);
     FIC_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_range_q, dim3(ngrp, g.planes), dim3(256), 0, s, (const uint8_t*)b.gray, b.rng_st, (float*)rngE, b.key,
-                       (uint32_t*)theta_g, (v4i*)rngQ, (uint32_t*)rngC, g, nct_alloc, grp0, mode);
+    // LDS staging of the byte copies when they fit beside the 16.6 KB of raw blocks (not at B = 16 with 8 isometries: 66 KB)
+    const size_t stage_bytes = (size_t)64 * fic_q_cols_per_range(g.B, g.n_iso) * (g.n + 8);
+    const int staged = stage_bytes <= 40 * 1024 ? 1 : 0;
+    hipLaunchKernelGGL(k_range_q, dim3(ngrp, g.planes), dim3(256), staged ? stage_bytes : 0, s, (const uint8_t*)b.gray, b.rng_st,
+                       (float*)rngE, b.key, (uint32_t*)theta_g, (v4i*)rngQ, (uint32_t*)rngC, g, nct_alloc, grp0, mode, staged);
     FIC_LAUNCH_CHECK();
     return 0;
 }
