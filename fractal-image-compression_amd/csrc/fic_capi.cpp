@@ -587,7 +587,9 @@ int fic_ctx_encode(fic_ctx* c, int range_begin, int range_count, void* hip_strea
         // FIC_SWEEP=5 means "the VALU-only default": k_sweep_d4 where it is built, else k_sweep_fast.
         const long long pairs = (long long)g.planes * range_count * g.Nd;
         const int valu = d4_available(g) ? 5 : 2;
-        kind = !g.full ? 1 : (pairs >= 2000000LL ? 6 : valu);
+        // (k_sweep_q's queue entries carry the domain block in 24 bits: pools of 2^24 blocks or more -- images beyond
+        //  16000 x 16000 at B = 8 -- stay on the VALU sweep)
+        kind = !g.full ? 1 : ((pairs >= 2000000LL && g.Nd < (1 << 24)) ? 6 : valu);
         const char* env = getenv("FIC_SWEEP");
         if (env && env[0] >= '2' && env[0] <= '6' && env[1] == '\0' && g.full) {
             const int want = env[0] - '0';
@@ -596,6 +598,7 @@ int fic_ctx_encode(fic_ctx* c, int range_begin, int range_count, void* hip_strea
     }
     if (kind >= 2 && !g.full) return fail(FIC_E_ARGUMENT, "fast sweep needs full search (wK == Dw == Dh)");
     if (kind == 5 && !d4_available(g)) return fail(FIC_E_ARGUMENT, "sweep 5 (k_sweep_d4) needs full search, n_iso = 8 and B = 8");
+    if (kind == 6 && g.Nd >= (1 << 24)) return fail(FIC_E_ARGUMENT, "sweep 6 (k_sweep_q) needs a pool of fewer than 2^24 blocks");
     const int tsz = 64 * g.NR;
     const int tile0 = range_begin / tsz;
     const int tile1 = (range_begin + range_count + tsz - 1) / tsz;

@@ -211,7 +211,7 @@ int fic_rgb_ctx_encode(fic_rgb_ctx* c, int with_collage, void* hip_stream)
     int want = c->opt_sweep;
     if (const char* env = getenv("FIC_RGB_SWEEP"))
         if (env[0] >= '1' && env[0] <= '2' && !env[1]) want = env[0] - '0';
-    const bool use_q = g.full && (want == 2 || (want == 0 && ((double)g.Nr * g.Nd >= 3e7 || g.B == 16)));
+    const bool use_q = g.full && g.Nd < (1 << 24) && (want == 2 || (want == 0 && ((double)g.Nr * g.Nd >= 3e7 || g.B == 16)));
     if (use_q && rgb_q_setup(c)) return FIC_E_HIP;
     if (use_q) rgb_q_chunks(c);
     if (!use_q && g.full && g.B <= 8 && !c->pool_cf) {      // the VALU full-search sweep's f32 pool copy (k_sweep_rgb_fast), on first use
