@@ -80,14 +80,15 @@ def csrc_hash():
     return h.hexdigest()[:12]
 
 
-def kernel_name(kind, B, n_iso):
+def kernel_name(kind, B, n_iso, chunks=1):
     if kind == 3:
         bf16 = B <= 8 or n_iso == 8
         return ("k_sweep_bf16" if bf16 else "k_sweep_mfma") + ("" if n_iso == 8 else ("_1" if bf16 else "1")), ("bf16" if bf16 else "i8")
     if kind == 4:
         return "k_sweep_mfma" + ("" if n_iso == 8 else "1"), "i8"
-    if kind == 6:     # k_sweep_q<NK, MODE>: NK = n/16 MFMA steps, MODE 0 = 1 isometry, 1 = 8 isometries (B = 4), 2 = 8 isometries folded
-        return f"k_sweep_q<{B * B // 16}, {0 if n_iso == 1 else (1 if B == 4 else 2)}>", "f16"
+    if kind == 6:     # k_sweep_q<NK, MODE, MULTI>: NK = n/16 MFMA steps, MODE 0 = 1 isometry, 1 = 8 isometries (B = 4), 2 = 8 isometries
+        # folded; MULTI: the launch has more than one pool chunk
+        return f"k_sweep_q<{B * B // 16}, {0 if n_iso == 1 else (1 if B == 4 else 2)}, {'true' if chunks > 1 else 'false'}>", "f16"
     return SWEEP_KINDS.get(kind, ("k_sweep_fast", None))[0], None
 
 
@@ -417,7 +418,7 @@ def main():
 
     if rank == 0:
         kind = info["sweep_kind"]
-        kname, operand = kernel_name(kind, B, n_iso)
+        kname, operand = kernel_name(kind, B, n_iso, info["chunks"])
         # The clock the chip holds under this sweep (outside the timed region): k_sweep_q's own counters, shader-clock cycles
         # over 100 MHz ticks of a sample of its waves.  Dense MFMA work is power-limited well below the 2.4 GHz the peak
         # figures assume, so the roofline block reports the fraction against both.
@@ -582,7 +583,7 @@ def single_image(fic_amd, torch, img, B, n_iso, device, sweep, reps=200):
     enc.close()
     return {"workload": f"one {W}x{H} synthetic grey U image, B={B}, full search, {n_iso} iso (BASELINE config 2 literally)",
             "ms": ms, "matches_per_s": nr / (ms * 1e-3), "latency_ms": lat[len(lat) // 2],
-            "sweep_ms": sw_ms / max(sw_n, 1), "kernel": kernel_name(info["sweep_kind"], B, n_iso)[0], "pool_chunks": info["chunks"],
+            "sweep_ms": sw_ms / max(sw_n, 1), "kernel": kernel_name(info["sweep_kind"], B, n_iso, info["chunks"])[0], "pool_chunks": info["chunks"],
             "note": "ms: HIP events around 200 back-to-back encodes (pool build + range prep + sweep + finalise each); "
                     "latency_ms: median host time of encode + sync"}
 

@@ -520,7 +520,9 @@ __device__ __forceinline__ float q_share_max(float v)
 // Launch bounds: the register budget is cut for FIC_Q_WAVES_* waves per SIMD (<= 256 VGPRs at B = 4 / 8), which also makes the
 // compiler emit the MFMAs with VGPR destinations whatever the build flags say (the library is built with -mllvm
 // -amdgpu-mfma-vgpr-form; with accumulators in AGPRs every element the epilogue tests costs a v_accvgpr_read first).
-template <int NK, int MODE>
+// MULTI: the launch has more than one pool chunk (theta_g is shared between the waves of a range); a one-chunk launch is a
+// separate instantiation without any of that code, see (3) in slow_tile.
+template <int NK, int MODE, bool MULTI>
 __global__ __launch_bounds__(64 * FIC_Q_WPG, NK == 4 ? FIC_Q_WAVES_B8 : (NK < 4 ? FIC_Q_WAVES_B4 : 1)) void k_sweep_q(QArgs A)
 {
     constexpr int CTW = fic_q_ctw(NK), CT = FIC_Q_WPG * CTW;
@@ -603,8 +605,11 @@ __global__ __launch_bounds__(64 * FIC_Q_WPG, NK == 4 ? FIC_Q_WAVES_B8 : (NK < 4 
         const bool mayraise = (raise >> ci) & 1u;
         const int colw = ci * 32 + jcol;                     // column in wave
         const int jg = ((ctw0 + ci) * 32 + jcol) >> CSHIFT;  // the column's range block (valid when ok)
-        // (3), consumed below so that the load overlaps the element loop; with one chunk no other wave sees this range
-        const uint32_t g = (mayraise && A.nchunks > 1) ? thg[jg] : 0u;
+        // (3), consumed at the end so that the load overlaps the element loop.  Waiting for it is s_waitcnt vmcnt(0), i.e. also a
+        // wait for the prefetched domain fragments (an L2 round trip per flagged tile): the one-chunk instantiation -- no other
+        // wave sees this range -- has no vector memory operation in a flagged tile at all.  (A run-time branch instead of a
+        // second instantiation makes the compiler tighten the vmcnt waits of the FAST path: tried, 8 % slower.)
+        const uint32_t g = (MULTI && mayraise) ? thg[jg] : 0u;
         const uint32_t ent0 = (uint32_t)(dt * 32 + 4 * half) | ((uint32_t)colw << 24);   // entry of element 0; element e adds its row
         if (first) {                                         // (1)
             const float lo = __fsub_rn(q_share_max<MODE>(ok ? mx : 0.0f), E[ci]);
@@ -644,9 +649,9 @@ __global__ __launch_bounds__(64 * FIC_Q_WPG, NK == 4 ? FIC_Q_WAVES_B8 : (NK < 4 
         if (mayraise && lo2 >= 0.0f) {
             const float lb = __fsub_rn(__fmul_rn(lo2, FIC_Q_LEVEL), E[ci]);
             tau[ci] = fmaxf(tau[ci], lb);
-            if (A.nchunks > 1 && lo2 >= lmin && half == 0 && (jcol & ((1 << CSHIFT) - 1)) == 0) atomicMax(&thg[jg], f32_orderable(lb));
+            if (MULTI && lo2 >= lmin && half == 0 && (jcol & ((1 << CSHIFT) - 1)) == 0) atomicMax(&thg[jg], f32_orderable(lb));
         }
-        if (mayraise && g != 0u) tau[ci] = fmaxf(tau[ci], f32_from_orderable(g));
+        if (MULTI && mayraise && g != 0u) tau[ci] = fmaxf(tau[ci], f32_from_orderable(g));
     };
     // accumulator(s) of one 32x32 tile: FOLD: even part from steps [0, NK/2), odd part from steps [NK/2, NK)
     auto tile_mfma = [&](const v4i (&at)[NK], const v4i (&bt)[NK], v16f& acc, v16f& acc2) __attribute__((always_inline)) {
@@ -672,8 +677,7 @@ __global__ __launch_bounds__(64 * FIC_Q_WPG, NK == 4 ? FIC_Q_WAVES_B8 : (NK < 4 
     tile_mfma(a0, rb[0], acc, acc2);
 
     // one domain tile (the fragment store has spare zero tiles behind the pool for the loop's overrun and the prefetch)
-    auto step = [&](int dt, v4i (&ac)[NK], const v4i (&an)[NK]) __attribute__((always_inline)) {
-        const bool first = dt == dt0;
+    auto step = [&](int dt, v4i (&ac)[NK], const v4i (&an)[NK], const bool first) __attribute__((always_inline)) {
 #pragma unroll
         for (int ci = 0; ci < CTW; ci++) {
             // the next tile's MFMAs: column tile ci+1 of this domain tile, or column tile 0 of the next domain tile
@@ -727,8 +731,8 @@ __global__ __launch_bounds__(64 * FIC_Q_WPG, NK == 4 ? FIC_Q_WAVES_B8 : (NK < 4 
         }
     };
     for (int dt = dt0; dt < dt1; dt += 2) {
-        step(dt, a0, a1);
-        step(dt + 1, a1, a0);
+        step(dt, a0, a1, dt == dt0);                         // first: a chunk's first tile (theta is seeded there)
+        step(dt + 1, a1, a0, false);
     }
     flush();
     if (A.stats && lane == 0) {
@@ -747,6 +751,27 @@ __global__ __launch_bounds__(64 * FIC_Q_WPG, NK == 4 ? FIC_Q_WAVES_B8 : (NK < 4 
 // ---------------------------------------------------------------------------------------------
 // host-side launchers
 // ---------------------------------------------------------------------------------------------
+template <int NK, int MODE>
+static void q_launch_nm(bool multi, dim3 grid, dim3 block, hipStream_t s, const QArgs& A)
+{
+    if (multi) hipLaunchKernelGGL((k_sweep_q<NK, MODE, true>), grid, block, 0, s, A);
+    else hipLaunchKernelGGL((k_sweep_q<NK, MODE, false>), grid, block, 0, s, A);
+}
+// NK = n / 16; mode 0 / 1 / 2 as fic_q_mode, 3 = joint RGB.  false: no such kernel
+static bool q_launch(int NK, int mode, bool multi, dim3 grid, dim3 block, hipStream_t s, const QArgs& A)
+{
+    if (NK == 1 && mode == 0) q_launch_nm<1, 0>(multi, grid, block, s, A);
+    else if (NK == 1 && mode == 1) q_launch_nm<1, 1>(multi, grid, block, s, A);
+    else if (NK == 1 && mode == 3) q_launch_nm<1, 3>(multi, grid, block, s, A);
+    else if (NK == 4 && mode == 0) q_launch_nm<4, 0>(multi, grid, block, s, A);
+    else if (NK == 4 && mode == 2) q_launch_nm<4, 2>(multi, grid, block, s, A);
+    else if (NK == 4 && mode == 3) q_launch_nm<4, 3>(multi, grid, block, s, A);
+    else if (NK == 16 && mode == 0) q_launch_nm<16, 0>(multi, grid, block, s, A);
+    else if (NK == 16 && mode == 2) q_launch_nm<16, 2>(multi, grid, block, s, A);
+    else if (NK == 16 && mode == 3) q_launch_nm<16, 3>(multi, grid, block, s, A);
+    else return false;
+    return true;
+}
 int fic_q_ct(int B) { return FIC_Q_WPG * fic_q_ctw(B * B / 16); }       // column tiles (x32 columns) per workgroup
 // 0: 1 isometry; 1: 8 isometries, one column per copy; 2: 8 isometries folded into 4 columns per range block
 int fic_q_mode(int B, int n_iso) { return n_iso == 1 ? 0 : (B == 4 ? 1 : 2); }
@@ -794,13 +819,7 @@ int fic_launch_sweep_q(const FicBuffers& b, const void* poolQ, const void* dflat
         return (int)hipErrorInvalidValue;
     dim3 grid((unsigned)(nchunks * g.planes) * (unsigned)A.nctg), block(64 * FIC_Q_WPG);
     const int mode = fic_q_mode(g.B, g.n_iso);
-    if (g.B == 4 && mode == 0) hipLaunchKernelGGL((k_sweep_q<1, 0>), grid, block, 0, s, A);
-    else if (g.B == 4 && mode == 1) hipLaunchKernelGGL((k_sweep_q<1, 1>), grid, block, 0, s, A);
-    else if (g.B == 8 && mode == 0) hipLaunchKernelGGL((k_sweep_q<4, 0>), grid, block, 0, s, A);
-    else if (g.B == 8 && mode == 2) hipLaunchKernelGGL((k_sweep_q<4, 2>), grid, block, 0, s, A);
-    else if (g.B == 16 && mode == 0) hipLaunchKernelGGL((k_sweep_q<16, 0>), grid, block, 0, s, A);
-    else if (g.B == 16 && mode == 2) hipLaunchKernelGGL((k_sweep_q<16, 2>), grid, block, 0, s, A);
-    else return (int)hipErrorInvalidValue;
+    if (!q_launch(g.B * g.B / 16, mode, nchunks > 1, grid, block, s, A)) return (int)hipErrorInvalidValue;
     FIC_LAUNCH_CHECK();
     return 0;
 }
@@ -943,10 +962,7 @@ int fic_launch_rgbq(const uint16_t* pool_sum, const FicRgbDomStat* pool_st, cons
     if (A.nctg * CT > nct_alloc || (nct_alloc & 1) || g.Nd >= (1 << 24) || A.ndtiles_loop + unroll > ndtiles_alloc || tiles_per_chunk % unroll)
         return (int)hipErrorInvalidValue;
     dim3 grid((unsigned)nchunks * (unsigned)A.nctg), block(64 * FIC_Q_WPG);
-    if (g.B == 4) hipLaunchKernelGGL((k_sweep_q<1, 3>), grid, block, 0, s, A);
-    else if (g.B == 8) hipLaunchKernelGGL((k_sweep_q<4, 3>), grid, block, 0, s, A);
-    else if (g.B == 16) hipLaunchKernelGGL((k_sweep_q<16, 3>), grid, block, 0, s, A);
-    else return (int)hipErrorInvalidValue;
+    if (!q_launch(g.B * g.B / 16, 3, nchunks > 1, grid, block, s, A)) return (int)hipErrorInvalidValue;
     FIC_LAUNCH_CHECK();
     return 0;
 }
