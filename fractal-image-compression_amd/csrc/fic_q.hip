@@ -529,7 +529,7 @@ __global__ __launch_bounds__(64 * FIC_Q_WPG, NK == 4 ? FIC_Q_WAVES_B8 : (NK < 4 
     constexpr int CSHIFT = QMode<MODE>::CSHIFT;
     constexpr bool FOLD = MODE == 2;
     constexpr int NKA = FOLD ? NK / 2 : NK;                  // MFMA steps per accumulator
-    __shared__ uint32_t sQ[FIC_Q_WPG][FIC_Q_QCAP];             // per wave: domain block | column-in-wave << 24
+    __shared__ uint32_t sQ[FIC_Q_WPG][FIC_Q_QCAP + 4];         // per wave: domain block | column-in-wave << 24; [QCAP] = fill count
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     int combo_, gx_;
@@ -549,6 +549,9 @@ __global__ __launch_bounds__(64 * FIC_Q_WPG, NK == 4 ? FIC_Q_WAVES_B8 : (NK < 4 
     const FicRngStat* rst = A.rng_st + (size_t)plane * A.Nr_pad;
     uint32_t* const thg = A.theta_g + (size_t)plane * A.Nr_pad;
     uint32_t* const myq = sQ[wave];
+    uint32_t* const myqn = myq + FIC_Q_QCAP;                 // the queue's fill count (the slow path allocates with ds_add_rtn)
+    const uint32_t myqn_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t*)myqn;   // its LDS byte address
+    if (lane == 0) *myqn = 0u;
 
     v4i rb[CTW][NK];
     {
@@ -586,7 +589,9 @@ __global__ __launch_bounds__(64 * FIC_Q_WPG, NK == 4 ? FIC_Q_WAVES_B8 : (NK < 4 
     auto flush = [&]() __attribute__((always_inline)) {
         q_flush<NK, MODE>(A, myq, qn, plane, ctw0, lane);
         qn = 0;
-    };
+        if (lane == 0) *myqn = 0u;
+        __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0): atomics left in flight here make the compiler tighten the
+    };                                                       // fast path's waits for the prefetched fragments
     // test value of element e: |q| (MODE 0/1) or |even| + |odd| = the larger |q| of the isometry pair (MODE 2)
     auto val = [&](const v16f& acc, const v16f& acc2, int e) __attribute__((always_inline)) {
         return FOLD ? fabsf(acc[e]) + fabsf(acc2[e]) : fabsf(acc[e]);
@@ -599,7 +604,6 @@ __global__ __launch_bounds__(64 * FIC_Q_WPG, NK == 4 ? FIC_Q_WAVES_B8 : (NK < 4 
     auto slow_tile = [&](const v16f& acc, const v16f& acc2, float mx, int ci, int dt, bool first) __attribute__((always_inline)) {
         // only zeros flagged (theta still "none"): an all-flat tile seen before anything was evaluated needs nothing
         if (!first && __builtin_amdgcn_ballot_w64(mx > 0.0f) == 0 && pflat[dt] != 0u) return;
-        if (qn > FIC_Q_QFLUSH) flush();
         st_slow++;
         const bool ok = (okbits >> ci) & 1u;
         const bool mayraise = (raise >> ci) & 1u;
@@ -626,22 +630,19 @@ __global__ __launch_bounds__(64 * FIC_Q_WPG, NK == 4 ? FIC_Q_WAVES_B8 : (NK < 4 
         if (!ok) hm = 0;
         if (cand0) hm |= 1u;
         const int cnt = __builtin_popcount(hm);
-        // queue offsets: exclusive prefix over the (few) lanes that have something, walked in SGPRs
-        unsigned long long lanes = __builtin_amdgcn_ballot_w64(cnt != 0);
-        int mybase = 0, total = 0;
-        while (lanes) {
-            const int L = __builtin_ctzll(lanes);
-            lanes &= lanes - 1;
-            const int cL = __builtin_amdgcn_readlane(cnt, L);
-            if (lane == L) mybase = total;
-            total += cL;
-        }
-        for (uint32_t h = hm, w = (uint32_t)(qn + mybase); h; h &= h - 1, w++) {
-            const int e = __builtin_ctz(h);
+        // Queue slots: every lane that has something takes cnt consecutive entries from the wave's fill count (an LDS atomic; no
+        // scalar walk over the lanes).  The first entry is written without a loop -- nearly always the only one.
+        if (cnt != 0) {
+            // (inline asm: as an atomicAdd the compiler's atomic optimiser turns it back into a scalar loop over the lanes)
+            uint32_t w;
+            asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(w) : "v"(myqn_lds), "v"((uint32_t)cnt) : "memory");
+            int e = __builtin_ctz(hm);
             myq[w] = ent0 + (uint32_t)((e & 3) + 8 * (e >> 2));
+            for (uint32_t h = hm & (hm - 1); h; h &= h - 1) {
+                e = __builtin_ctz(h);
+                myq[++w] = ent0 + (uint32_t)((e & 3) + 8 * (e >> 2));
+            }
         }
-        qn += total;
-        st_pairs += (unsigned)total;
         // a lane with flagged elements has its largest element among them: that is mx
         const float mp = cnt != 0 ? mx : -1.0f;
         // (2): level of the best flagged entry, shared by the lanes of the range
@@ -652,6 +653,11 @@ __global__ __launch_bounds__(64 * FIC_Q_WPG, NK == 4 ? FIC_Q_WAVES_B8 : (NK < 4 
             if (MULTI && lo2 >= lmin && half == 0 && (jcol & ((1 << CSHIFT) - 1)) == 0) atomicMax(&thg[jg], f32_orderable(lb));
         }
         if (MULTI && mayraise && g != 0u) tau[ci] = fmaxf(tau[ci], f32_from_orderable(g));
+        // the fill count after this tile (LDS operations of a wave complete in order); one tile adds at most 1024 entries
+        const int tot = __builtin_amdgcn_readfirstlane((int)*(volatile __attribute__((address_space(3))) uint32_t*)(__attribute__((address_space(3))) uint32_t*)myqn);   // ds_read, not a flat load
+        st_pairs += (unsigned)(tot - qn);
+        qn = tot;
+        if (qn > FIC_Q_QFLUSH) flush();
     };
     // accumulator(s) of one 32x32 tile: FOLD: even part from steps [0, NK/2), odd part from steps [NK/2, NK)
     auto tile_mfma = [&](const v4i (&at)[NK], const v4i (&bt)[NK], v16f& acc, v16f& acc2) __attribute__((always_inline)) {
