@@ -136,3 +136,35 @@ def test_default_selection_and_batches(oracle, lena_colored):
         with pytest.raises(fic_amd.FicError):
             enc.set_option("sweep", 3)
     fic_amd.capi.release_cache()
+
+
+def test_seeded_fuzz_rgb_full_search(oracle):
+    """Random (size, B, image kind, chunk count) colour cases: both full-search sweeps against the oracle's encodeRGB."""
+    import os
+    rng = np.random.default_rng(int(os.environ.get("FIC_FUZZ_SEED", "20261004")))
+    for _ in range(int(os.environ.get("FIC_FUZZ_CASES", "40"))):
+        B = int(rng.choice([4, 8, 16]))
+        R = int(rng.integers(2, 144 // B + 1))
+        size = R * B
+        kind = rng.choice(["U", "S", "low", "ramp", "const"])
+        seed = int(rng.integers(1, 1 << 30))
+        if kind in ("U", "S"):
+            rgb = _rgb_synth(size, size, seed, flat=(kind == "S"))
+        elif kind == "low":
+            bits, cell = int(rng.integers(1, 4)), int(rng.choice([1, 2, 4]))
+            n = -(-size // cell)
+            low = rng.integers(0, 1 << bits, (n, n, 3), dtype=np.uint8)
+            rgb = (np.repeat(np.repeat(low, cell, 0), cell, 1)[:size, :size] * (255 // ((1 << bits) - 1))).astype(np.uint8)
+        elif kind == "ramp":
+            y, x = np.mgrid[0:size, 0:size]
+            rgb = np.stack([(x * 3 + seed) % 256, (y * 5 + x) % 256, (x + y + seed) % 256], -1).astype(np.uint8)
+        else:
+            rgb = np.full((size, size, 3), (seed % 256, (seed >> 8) % 256, (seed >> 16) % 256), np.uint8)
+        argb = oracle.rgb_to_argb(np.ascontiguousarray(rgb))
+        ref = _oracle_dict(oracle, argb, size, size, B)
+        for sweep in (1, 2):
+            chunks = int(rng.integers(0, 6)) if sweep == 2 else 0
+            try:
+                _same(_encode([argb], size, size, B, sweep, chunks), ref, 0)
+            except AssertionError as e:
+                raise AssertionError(f"case size={size} B={B} kind={kind} seed={seed} sweep={sweep} chunks={chunks}: {e}")
