@@ -8,8 +8,8 @@ extern "C" {
 
 // ---- joint-RGB encode (encodeRGB FC:171-219) -----------------------------------------------------
 // A context owns the device working set of `planes` colour images of one geometry (config-5 style batches; the one-shot
-// entry keeps a few single-image contexts).  The kernels are per image: a batch is their launch sequence per plane on the
-// caller's stream.  The covariance sums stay sequential f32 in the reference's order (FC:781-792: they exceed 2^24).
+// entry keeps a few single-image contexts).  The kernels take the image from their grid: a batch is one launch per stage on the
+// caller's stream (only the matrix-core full search runs image by image).  The covariance sums stay sequential f32 in the reference's order (FC:781-792: they exceed 2^24).
 struct fic_rgb_ctx {
     int device = 0;
     FicGeom g;
@@ -204,8 +204,6 @@ int fic_rgb_ctx_encode(fic_rgb_ctx* c, int with_collage, void* hip_stream)
     hipStream_t s = (hipStream_t)hip_stream;
     c->last_stream = s;
     const FicGeom& g = c->g;
-    FicGeom g1 = g;
-    g1.planes = 1;
     // Full search: the matrix-core sweep where it pays (its prep costs ~50 us; the VALU sweep does ~1e11 pairs/s), or where
     // the VALU full-search kernel does not exist (B = 16).  FIC_RGB_SWEEP=1|2 / option "sweep" override.
     int want = c->opt_sweep;
@@ -219,12 +217,12 @@ int fic_rgb_ctx_encode(fic_rgb_ctx* c, int with_collage, void* hip_stream)
         if (rc != FIC_OK) return rc;
     }
     c->last_sweep = use_q ? 2 : 1;
-    for (int p = 0; p < g.planes; p++) {
-        FicRgbBuffers b;
+    {
+        FicRgbBuffers b;                                  // image 0 of the batch: the kernels take the image from their grid
         FicRgbOutputs o;
-        rgb_plane(c, p, &b, &o);
-        if (fic_launch_rgb_encode(b, o, with_collage ? c->collage + (size_t)p * g.W * g.H : nullptr, g1, s, use_q ? &c->q : nullptr))
-            return fail(FIC_E_HIP, "RGB kernel launch failed (plane %d)", p);
+        rgb_plane(c, 0, &b, &o);
+        if (fic_launch_rgb_encode(b, o, with_collage ? c->collage : nullptr, g, s, use_q ? &c->q : nullptr))
+            return fail(FIC_E_HIP, "RGB kernel launch failed");
     }
     c->encoded_any = true;
     c->have_collage = with_collage != 0;

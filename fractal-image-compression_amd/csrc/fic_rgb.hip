@@ -30,6 +30,8 @@ __global__ __launch_bounds__(256) void k_scale_rgb(const int32_t* __restrict__ a
 {
     int xs = blockIdx.x * 256 + threadIdx.x, ys = blockIdx.y;
     if (xs >= g.Ws) return;
+    argb += (size_t)blockIdx.z * g.W * g.H;                               // blockIdx.z = image of the batch
+    scaled += (size_t)blockIdx.z * g.Ws * g.Hs;
     int x = 2 * xs, y = 2 * ys;
     int32_t p00 = argb[x + (size_t)y * g.W], p10 = argb[x + 1 + (size_t)y * g.W], p01 = argb[x + (size_t)(y + 1) * g.W];
     bool edge = (x + 1 >= g.H);
@@ -45,6 +47,9 @@ __global__ __launch_bounds__(256) void k_pool_rgb(const int32_t* __restrict__ sc
 {
     int d = blockIdx.x * 256 + threadIdx.x;
     if (d >= g.Nd) return;
+    scaled += (size_t)blockIdx.y * g.Ws * g.Hs;                           // blockIdx.y = image of the batch
+    pool_sum += (size_t)blockIdx.y * g.Nd * g.n;
+    st += (size_t)blockIdx.y * g.Nd;
     int c = d % g.Dw, r = d / g.Dw;
     const int32_t* src = scaled + (size_t)(r * g.abstand) * g.Ws + c * g.abstand;
     int sR = 0, sG = 0, sB = 0;
@@ -77,6 +82,9 @@ __global__ __launch_bounds__(256) void k_range_rgb(const int32_t* __restrict__ a
 {
     int j = blockIdx.x * 256 + threadIdx.x;
     if (j >= g.Nr) return;
+    argb += (size_t)blockIdx.y * g.W * g.H;                               // blockIdx.y = image of the batch
+    rng_t += (size_t)blockIdx.y * g.Nr * g.n;
+    st += (size_t)blockIdx.y * g.Nr;
     const int32_t* im = argb + (size_t)((j / g.Rw) * g.B) * g.W + (j % g.Rw) * g.B;
     int sR = 0, sG = 0, sB = 0;
     for (int y = 0; y < g.B; y++)
@@ -114,6 +122,11 @@ __global__ __launch_bounds__(256) void k_sweep_rgb(const uint16_t* __restrict__ 
     int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     int j = blockIdx.x * 4 + wave;
     if (j >= g.Nr) return;
+    pool_sum += (size_t)blockIdx.y * g.Nd * g.n;                          // blockIdx.y = image of the batch
+    dst += (size_t)blockIdx.y * g.Nd;
+    rng_t += (size_t)blockIdx.y * g.Nr * g.n;
+    rst += (size_t)blockIdx.y * g.Nr;
+    key += (size_t)blockIdx.y * g.Nr;
     FicRgbRngStat rs = rst[j];
     const int16_t* rt = rng_t + (size_t)j * g.n;
     float vRf = (float)rs.vR;
@@ -152,6 +165,9 @@ __global__ __launch_bounds__(256) void k_pool_rgb_centred(const uint16_t* __rest
 {
     size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= (size_t)g.Nd * g.n) return;
+    pool_sum += (size_t)blockIdx.y * g.Nd * g.n;                          // blockIdx.y = image of the batch
+    pool_cf += (size_t)blockIdx.y * g.Nd * g.n;
+    st += (size_t)blockIdx.y * g.Nd;
     pool_cf[i] = (float)((int)pool_sum[i] - st[i >> g.lgn].msum);           // greyD_i, |.| <= 765: exact
 }
 
@@ -163,6 +179,11 @@ __global__ __launch_bounds__(256) void k_sweep_rgb_fast(const float* __restrict_
     const int lane = threadIdx.x & 63;
     const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);                  // 64 range blocks per wave
     if (tile * 64 >= g.Nr) return;
+    pool_cf += (size_t)blockIdx.z * g.Nd * N;                             // blockIdx.z = image of the batch
+    dst += (size_t)blockIdx.z * g.Nd;
+    rng_t += (size_t)blockIdx.z * g.Nr * N;
+    rst += (size_t)blockIdx.z * g.Nr;
+    key += (size_t)blockIdx.z * g.Nr;
     const int j = tile * 64 + lane;
     const int jj = j < g.Nr ? j : g.Nr - 1;                                // tail lanes shadow the last block
     const int d0 = blockIdx.y * chunk_len;
@@ -201,6 +222,12 @@ __global__ __launch_bounds__(256) void k_finalize_rgb(const uint16_t* __restrict
 {
     int j = blockIdx.x * 256 + threadIdx.x;
     if (j >= g.Nr) return;
+    {
+        const size_t p = blockIdx.y;                                      // image of the batch
+        pool_sum += p * g.Nd * g.n; dst += p * g.Nd; rng_t += p * g.Nr * g.n; rst += p * g.Nr; key += p * g.Nr;
+        out.idx_local += p * g.Nr; out.idx_global += p * g.Nr; out.a += p * g.Nr; out.bR += p * g.Nr; out.bG += p * g.Nr;
+        out.bB += p * g.Nr; out.qrows += p * g.Nr * 5;
+    }
     int c = (int)(uint32_t)key[j];
     int gi = window_to_global(g, j, c);
     FicRgbDomStat ds = dst[gi];
@@ -232,6 +259,11 @@ __global__ __launch_bounds__(256) void k_collage_rgb(const int32_t* __restrict__
 {
     int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
     if (x >= g.W) return;
+    {
+        const size_t p = blockIdx.z;                                      // image of the batch
+        scaled += p * g.Ws * g.Hs; collage += p * g.W * g.H;
+        out.idx_global += p * g.Nr; out.a += p * g.Nr; out.bR += p * g.Nr; out.bG += p * g.Nr; out.bB += p * g.Nr;
+    }
     int j = (y / g.B) * g.Rw + (x / g.B);
     int rx = x % g.B, ry = y % g.B;
     int gi = out.idx_global[j];
@@ -298,37 +330,44 @@ __global__ __launch_bounds__(256) void k_decode_paint_rgb(const int32_t* __restr
 }
 
 // host-side launchers
-// joint-RGB encode, single image: scale, pool, ranges, sweep, finalise (+ collage when asked)
+// joint-RGB encode of g.planes images (buffers: image p at p x the per-image size): scale, pool, ranges, sweep, finalise
+// (+ collage when asked).  Every kernel takes the image from the grid, so a batch costs one launch per stage, not per image;
+// only the matrix-core full search runs image by image (its fragment buffers hold one image; it is the choice for big ones).
 int fic_launch_rgb_encode(const FicRgbBuffers& b, const FicRgbOutputs& out, int32_t* collage, const FicGeom& g,
                           hipStream_t s, const FicRgbQ* q)
 {
-    hipLaunchKernelGGL(k_scale_rgb, dim3((g.Ws + 255) / 256, g.Hs), dim3(256), 0, s, (const int32_t*)b.argb, b.scaled, g);
+    const unsigned P = (unsigned)g.planes;
+    hipLaunchKernelGGL(k_scale_rgb, dim3((g.Ws + 255) / 256, g.Hs, P), dim3(256), 0, s, (const int32_t*)b.argb, b.scaled, g);
     FIC_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_pool_rgb, dim3((g.Nd + 255) / 256), dim3(256), 0, s, (const int32_t*)b.scaled, b.pool_sum,
+    hipLaunchKernelGGL(k_pool_rgb, dim3((g.Nd + 255) / 256, P), dim3(256), 0, s, (const int32_t*)b.scaled, b.pool_sum,
                        b.pool_st, g);
     FIC_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_range_rgb, dim3((g.Nr + 255) / 256), dim3(256), 0, s, (const int32_t*)b.argb, b.rng_t, b.rng_st, g);
+    hipLaunchKernelGGL(k_range_rgb, dim3((g.Nr + 255) / 256, P), dim3(256), 0, s, (const int32_t*)b.argb, b.rng_t, b.rng_st, g);
     FIC_LAUNCH_CHECK();
     if (g.full && q && q->poolQ) {
         // full search on the matrix cores (fic_q.hip, k_sweep_q<NK, 3>): the MFMA output prunes, flagged pairs are evaluated
         // with the reference's sequential f32 sums
-        if (fic_launch_rgbq(b.pool_sum, b.pool_st, b.rng_t, b.rng_st, b.key, q->poolQ, q->dflat, q->rngQ, q->qst, q->rngE, q->theta_g,
-                            q->amax, g, q->ndtiles, q->ndtiles_alloc, q->nct_alloc, q->tiles_per_chunk, q->nchunks, s))
-            return (int)hipErrorUnknown;
+        FicGeom g1 = g;
+        g1.planes = 1;
+        for (size_t p = 0; p < P; p++)
+            if (fic_launch_rgbq(b.pool_sum + p * g.Nd * g.n, b.pool_st + p * g.Nd, b.rng_t + p * g.Nr * g.n, b.rng_st + p * g.Nr,
+                                b.key + p * g.Nr, q->poolQ, q->dflat, q->rngQ, q->qst, q->rngE, q->theta_g, q->amax, g1, q->ndtiles,
+                                q->ndtiles_alloc, q->nct_alloc, q->tiles_per_chunk, q->nchunks, s))
+                return (int)hipErrorUnknown;
     } else if (g.full && g.B <= 8 && b.pool_cf) {
         // full search: lane = range block, wave-uniform domain blocks, pool chunks across workgroups
         const size_t total = (size_t)g.Nd * g.n;
-        hipLaunchKernelGGL(k_pool_rgb_centred, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s,
+        hipLaunchKernelGGL(k_pool_rgb_centred, dim3((unsigned)((total + 255) / 256), P), dim3(256), 0, s,
                            (const uint16_t*)b.pool_sum, (const FicRgbDomStat*)b.pool_st, b.pool_cf, g);
         FIC_LAUNCH_CHECK();
-        if (hipMemsetAsync(b.key, 0xFF, (size_t)g.Nr * sizeof(unsigned long long), s) != hipSuccess) return (int)hipErrorUnknown;
+        if (hipMemsetAsync(b.key, 0xFF, (size_t)P * g.Nr * sizeof(unsigned long long), s) != hipSuccess) return (int)hipErrorUnknown;
         const int tiles = (g.Nr + 63) / 64;
-        int nchunks = (8192 + tiles - 1) / tiles;                          // ~8 waves per SIMD
+        int nchunks = (8192 + tiles * (int)P - 1) / (tiles * (int)P);      // ~8 waves per SIMD
         if (nchunks > g.Nd / 64) nchunks = g.Nd / 64;
         if (nchunks < 1) nchunks = 1;
         const int chunk_len = (g.Nd + nchunks - 1) / nchunks;
         nchunks = (g.Nd + chunk_len - 1) / chunk_len;
-        dim3 grid((tiles + 3) / 4, nchunks);
+        dim3 grid((tiles + 3) / 4, nchunks, P);
         if (g.B == 4)
             hipLaunchKernelGGL((k_sweep_rgb_fast<16>), grid, dim3(256), 0, s, (const float*)b.pool_cf, (const FicRgbDomStat*)b.pool_st,
                                (const int16_t*)b.rng_t, (const FicRgbRngStat*)b.rng_st, b.key, g, chunk_len);
@@ -336,16 +375,16 @@ int fic_launch_rgb_encode(const FicRgbBuffers& b, const FicRgbOutputs& out, int3
             hipLaunchKernelGGL((k_sweep_rgb_fast<64>), grid, dim3(256), 0, s, (const float*)b.pool_cf, (const FicRgbDomStat*)b.pool_st,
                                (const int16_t*)b.rng_t, (const FicRgbRngStat*)b.rng_st, b.key, g, chunk_len);
     } else {
-        hipLaunchKernelGGL(k_sweep_rgb, dim3((g.Nr + 3) / 4), dim3(256), 0, s, (const uint16_t*)b.pool_sum,
+        hipLaunchKernelGGL(k_sweep_rgb, dim3((g.Nr + 3) / 4, P), dim3(256), 0, s, (const uint16_t*)b.pool_sum,
                            (const FicRgbDomStat*)b.pool_st, (const int16_t*)b.rng_t, (const FicRgbRngStat*)b.rng_st, b.key, g);
     }
     FIC_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_finalize_rgb, dim3((g.Nr + 255) / 256), dim3(256), 0, s, (const uint16_t*)b.pool_sum,
+    hipLaunchKernelGGL(k_finalize_rgb, dim3((g.Nr + 255) / 256, P), dim3(256), 0, s, (const uint16_t*)b.pool_sum,
                        (const FicRgbDomStat*)b.pool_st, (const int16_t*)b.rng_t, (const FicRgbRngStat*)b.rng_st,
                        (const unsigned long long*)b.key, out, g);
     FIC_LAUNCH_CHECK();
     if (collage) {
-        hipLaunchKernelGGL(k_collage_rgb, dim3((g.W + 255) / 256, g.H), dim3(256), 0, s, (const int32_t*)b.scaled, out,
+        hipLaunchKernelGGL(k_collage_rgb, dim3((g.W + 255) / 256, g.H, P), dim3(256), 0, s, (const int32_t*)b.scaled, out,
                            collage, g);
         FIC_LAUNCH_CHECK();
     }
