@@ -132,3 +132,27 @@ def test_whole_codebook_at_full_size_valu_equals_matrix_core(size, B, n_iso, dis
     assert len(np.unique(res[2]["idx_local"])) > {"S": 10, "lena": 300, "U": 1000}[dist]   # (tiled Lena repeats itself)
     if n_iso == 8 and dist == "U":
         assert len(np.unique(res[2]["iso"])) == 8
+
+
+def test_beyond_the_named_sizes_8192_B8(oracle):
+    """Four times config 4's pool: 8192 x 8192, B = 8 -- 1 048 576 range blocks x 4 182 025 domain blocks (22 bits of the 24 that
+    k_sweep_q's queue entries carry).  A range span through the default sweep: independent of the chunk count, equal to the
+    VALU sweep, and three of its rows equal to the oracle's scan of the FULL pool."""
+    g = synth.image_u(8192, 8192, 0xF1C0008)
+    with fic_amd.Encoder(8192, 8192, 8, None, 1) as enc:
+        assert (enc.n_ranges, enc.n_domains, enc.wK) == (1048576, 4182025, 2045)
+        enc.set_gray(g)
+        b, c = 524288 - 128, 512
+        base = _span(enc, b, c)
+        assert enc.info()["sweep_kind"] == 6
+        for chunks in (1, 9):
+            enc.set_option("chunks", chunks)
+            _same(_span(enc, b, c), base)
+        enc.set_option("chunks", 0)
+        enc.set_option("sweep", 2)
+        _same(_span(enc, b, 128), {k: v[:128] for k, v in base.items()})
+    ref = _oracle_rows(oracle, g, 8, 2045, 1, [b, b + 255, b + 511])
+    for j, (idx, ab, iso, err) in ref.items():
+        o = j - b
+        assert base["idx_local"][o] == idx and same_f32(np.array([base["a"][o], base["b"][o]]), ab)
+        assert same_f32(np.array([base["err"][o]]), np.array([err]))
