@@ -348,14 +348,15 @@ __global__ __launch_bounds__(256) void k_range_q(const uint8_t* __restrict__ gra
 
 // ---------------------------------------------------------------------------------------------
 // k_sweep_q<NK, MODE>      MODE 0: 1 isometry (the reference algorithm); 1: 8 isometries, one column per copy (B = 4);
-//                          2: 8 isometries folded by the point reflection (B = 8 / 16; see the header)
-//   rows (A) = 32 consecutive domain blocks, streamed from L2/HBM (three VGPR buffers in rotation);
+//                          2: 8 isometries folded by the point reflection (B = 8 / 16; see the header); 3: joint RGB (end of file)
+//   rows (A) = 32 consecutive domain blocks, streamed from L2/HBM (two VGPR buffers; a buffer is reloaded as soon as its
+//              last MFMAs have issued);
 //   cols (B) = 32 range columns (a copy, or in MODE 2 an isometry pair); a wave keeps the fragments of its CTW column tiles
 //              in VGPRs for the whole sweep, a workgroup = 4 waves = 4*CTW column tiles.
 //   acc[e] of lane (col = lane&31, half = lane>>5) belongs to (column col, domain block 32*dt + (e&3) + 8(e>>2) + 4*half);
 //   MODE 2 has two accumulators per tile (even / odd part, NK/2 MFMAs each) and tests |even| + |odd|.
 //   theta of the lane's range sits in one VGPR per column tile; the lanes that share a range (two halves x the range's
-//   columns) exchange raised values through LDS (ds_max on an order-preserving integer image) when something is flagged.
+//   columns) exchange raised values by DPP quad permutes + v_permlane32_swap when something is flagged (no LDS).
 //   The next tile's MFMAs are issued interleaved with the current tile's epilogue (sched_group_barrier).
 // ---------------------------------------------------------------------------------------------
 struct QArgs {
