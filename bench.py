@@ -14,16 +14,22 @@ gather per step (the path's only exchange), overlapped with the next 
 `--workload cfg4 --scaling strong` shards ONE 4096x4096 image's range blocks across the ranks.
 
 Launch: `python bench.py --gpus N` from a bare shell starts its own N rank processes (fresh
-children, spawned before this process touches torch or the GPU; it waits for them and exits
-with their worst code); under `python -m torch.distributed.run ... bench.py --gpus N` the
-RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* environment is used as given.
+children, spawned before this process touches torch or the GPU; it waits for them -- at most
+FIC_BENCH_TIMEOUT seconds, default 900 -- and exits with their worst code); under
+`python -m torch.distributed.run ... bench.py --gpus N` the RANK / LOCAL_RANK / WORLD_SIZE /
+MASTER_* environment is used as given.  Every rank carries a watchdog with the same deadline.
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (the compute
-bound of the sweep kernel that ran: matrix-core FLOP/s against the dense MFMA peak, or VALU
-issue for the VALU-only sweeps), `roofline_hbm_logical` (SURVEY 8d's byte model, which the
-sweep exceeds by the register-tile reuse factor), `valu_only` (the same workload through the
-VALU-only sweep north_star describes), `single_image` and `cpu_baseline` (the C oracle, 1 core,
-bounded sample).
+Prints ONE JSON line on rank 0 (contract in the task statement).  Beside the contract's keys:
+  roofline              the compute bound of the sweep kernel that ran (matrix-core FLOP/s against the dense MFMA peak, or
+                        VALU issue for the VALU-only sweeps): `frac` algorithmic, `executed_frac` what the matrix cores issue
+  roofline_hbm_logical  SURVEY 8d's byte model, which the sweep exceeds by the register-tile reuse factor
+  verified              the codebook of the timed configuration, re-encoded after the timed region by the VALU-only sweep
+                        (another kernel family) and compared record by record on the device
+  sustained             the same step loop for >= 2 s of wall time, with the clock the chip held during it
+  other_configs         BASELINE.json configs 3, 4 (8 and 1 isometries), 5: a few steps each (N = 1)
+  strong_cfg4           config 4 range-sharded over the N ranks through the same gather (every N): north_star's
+                        strong-scaling point
+  valu_only, pipelined, single_image, cpu_baseline (the C oracle, 1 core, bounded sample)
 """
 import argparse
 import hashlib
@@ -32,6 +38,7 @@ import os
 import socket
 import subprocess
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -54,6 +61,7 @@ WORKLOADS = {
     "cfg5": dict(W=1024, H=1024, B=8, n_iso=8, planes=24, scaling="weak", seed="cfg5",
                  desc="cfg5: 1024x1024 grey planes (RGB channels encoded independently), B=8, full search, 8 iso, 24 planes (8 RGB images) per GPU"),
 }
+OTHER_CONFIGS = ["cfg3", "cfg4", "cfg4iso1", "cfg5"]          # timed after the headline at N = 1 (`other_configs`)
 
 HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "i8": 5000.0}   # dense peaks, MI355X_MICROARCH.md "Matrix cores"
@@ -103,19 +111,43 @@ def _free_port():
     return p
 
 
-def launch_ranks(n, cmd, env=None, poll_s=0.2):
+def bench_timeout_s():
+    try:
+        return float(os.environ.get("FIC_BENCH_TIMEOUT", "900"))
+    except ValueError:
+        return 900.0
+
+
+def launch_ranks(n, cmd, env=None, poll_s=0.2, deadline_s=None):
     """Starts `cmd` n times as fresh child processes with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT
     set (one process per GPU; rendezvous on 127.0.0.1), waits for all of them and returns the worst exit code.  If a
-    rank fails, the others are stopped (their exact PIDs) instead of being left at a barrier.  The calling process
-    must not have touched the GPU: nothing here imports torch or loads libfic_hip.so."""
+    rank fails, the others are stopped (their exact PIDs) instead of being left at a barrier; if the ranks are still
+    running after `deadline_s` (FIC_BENCH_TIMEOUT, default 900 s) -- a rendezvous or a collective that never
+    completes -- the launcher says which ranks were alive, stops them and returns 124.  The calling process must not
+    have touched the GPU: nothing here imports torch or loads libfic_hip.so."""
     base = dict(os.environ if env is None else env)
     base.update(WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    deadline_s = bench_timeout_s() if deadline_s is None else deadline_s
     procs = []
     for r in range(n):
         e = dict(base, RANK=str(r), LOCAL_RANK=str(r))
         procs.append(subprocess.Popen(cmd, env=e))
+    t_end = time.time() + deadline_s
     worst = 0
     live = set(range(n))
+
+    def stop(which):
+        for o in sorted(which):
+            procs[o].terminate()
+        t_kill = time.time() + 10.0
+        left = set(which)
+        while left and time.time() < t_kill:
+            left = {r for r in left if procs[r].poll() is None}
+            time.sleep(poll_s)
+        for o in sorted(left):
+            procs[o].kill()
+            procs[o].wait()
+
     while live:
         for r in sorted(live):
             rc = procs[r].poll()
@@ -124,20 +156,37 @@ def launch_ranks(n, cmd, env=None, poll_s=0.2):
             live.discard(r)
             if rc != 0:
                 worst = worst or (rc if rc > 0 else 128 - rc)
-                for o in sorted(live):            # a failed rank leaves the others waiting at a collective
-                    procs[o].terminate()
-        if live:
+        if live and worst:                       # a failed rank leaves the others waiting at a collective
+            stop(live)
+            live = set()
+        elif live and time.time() > t_end:
+            print(f"bench.py launcher: deadline of {deadline_s:.0f} s passed with ranks {sorted(live)} of {n} still running "
+                  f"(FIC_BENCH_TIMEOUT); stopping them", file=sys.stderr, flush=True)
+            stop(live)
+            live = set()
+            worst = worst or 124
+        elif live:
             time.sleep(poll_s)
-            if worst:
-                deadline = time.time() + 10.0
-                while live and time.time() < deadline:
-                    live = {r for r in live if procs[r].poll() is None}
-                    time.sleep(poll_s)
-                for o in sorted(live):
-                    procs[o].kill()
-                    procs[o].wait()
-                live = set()
     return worst
+
+
+class Watchdog:
+    """Per-rank deadline (FIC_BENCH_TIMEOUT): a rank that is still running when it passes reports the stage it was in and
+    exits with code 124, so that whatever launched the ranks (launch_ranks above, torch.distributed.run) sees a failure
+    instead of waiting for a collective that never completes."""
+
+    def __init__(self, rank, seconds):
+        self.stage, self.rank = "start", rank
+        self.t = threading.Timer(seconds, self._fire)
+        self.t.daemon = True
+        self.t.start()
+
+    def _fire(self):
+        print(f"bench.py rank {self.rank}: still running after FIC_BENCH_TIMEOUT in stage '{self.stage}'; giving up", file=sys.stderr, flush=True)
+        os._exit(124)
+
+    def cancel(self):
+        self.t.cancel()
 
 
 # ----------------------------------------------------------------------------------------------------------------
@@ -187,8 +236,11 @@ def probe(args, world, rank):
     import torch
     import torch.distributed as dist
     import fic_amd
+    if args.probe_hang_rank is not None and rank == args.probe_hang_rank:
+        time.sleep(3600)                       # a rank that never reaches the rendezvous
     if world > 1:
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from datetime import timedelta
+        dist.init_process_group("gloo", rank=rank, world_size=world, timeout=timedelta(seconds=120))
     spans = fic_amd.shard_spans(1000, 64, world)
     b, c = spans[rank]
     rec = torch.from_numpy(np.arange(b * 6, (b + c) * 6, dtype=np.int32).reshape(1, c, 6))
@@ -228,13 +280,332 @@ def parse_args(argv=None):
     ap.add_argument("--pipeline", type=int, default=1, choices=[1, 2],
                     help="contexts/streams that take the steps alternately (2: prep of step k+1 overlaps the tail of sweep k)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-alt", action="store_true", help="skip the extra timings (valu_only, single_image)")
+    ap.add_argument("--no-alt", action="store_true", help="skip the extra timings (valu_only, pipelined, single_image, sustained, other_configs)")
+    ap.add_argument("--no-extra", action="store_true", help="skip other_configs / strong_cfg4 only")
+    ap.add_argument("--no-verify", action="store_true", help="skip the post-run codebook check")
+    ap.add_argument("--sustain", type=float, default=2.0, help="seconds of the `sustained` block (0 = skip)")
+    ap.add_argument("--extra-steps", type=int, default=3, help="timed steps of every other_configs / strong_cfg4 entry")
+    ap.add_argument("--extra-size", type=int, default=None, help=argparse.SUPPRESS)   # tests: shrink cfg3/cfg4 images
     ap.add_argument("--cpu-budget", type=float, default=12.0)
     ap.add_argument("--inproc", action="store_true",
                     help="time the in-library multi-device entry fic_encode_gray_u8_multi (one process, --gpus devices) instead")
     ap.add_argument("--probe", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--probe-fail-rank", type=int, default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--probe-hang-rank", type=int, default=None, help=argparse.SUPPRESS)
     return ap.parse_args(argv)
+
+
+# ----------------------------------------------------------------------------------------------------------------
+class Env:
+    """What every Run needs to know about this rank."""
+
+    def __init__(self, args, world, rank, local_rank, backend, dist, fic_amd, torch, np, watchdog):
+        self.args, self.world, self.rank, self.local_rank, self.backend, self.dist = args, world, rank, local_rank, backend, dist
+        self.fic_amd, self.torch, self.np, self.watchdog = fic_amd, torch, np, watchdog
+
+    def barrier(self):
+        if self.dist:
+            if self.backend == "nccl":
+                self.dist.barrier(device_ids=[self.local_rank])
+            else:
+                self.dist.barrier()
+
+    def max_over_ranks(self, x):
+        if not self.dist:
+            return x
+        t = self.torch.tensor([x], dtype=self.torch.float64, device="cuda" if self.backend == "nccl" else "cpu")
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def min_over_ranks(self, x):
+        if not self.dist:
+            return x
+        t = self.torch.tensor([x], dtype=self.torch.float64, device="cuda" if self.backend == "nccl" else "cpu")
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN)
+        return float(t.item())
+
+    def gather_floats(self, x):
+        if not self.dist:
+            return [x]
+        mine = self.torch.tensor([x], dtype=self.torch.float64, device="cuda" if self.backend == "nccl" else "cpu")
+        allv = [self.torch.zeros_like(mine) for _ in range(self.world)]
+        self.dist.all_gather(allv, mine)
+        return [float(v.item()) for v in allv]
+
+
+class Run:
+    """One workload on this rank: the synthetic batch resident in HBM, `ncontexts` encoder contexts with a compute stream
+    each, and the step loop (encode + codebook gather).  Used for the headline and for every extra block, so that every
+    number in the line comes from the same code."""
+
+    def __init__(self, env, wl, scaling, ncontexts=1, sweep=0, chunks=0, dist_kind="U"):
+        torch, fic_amd, np = env.torch, env.fic_amd, env.np
+        self.env, self.wl, self.scaling, self.sweep = env, wl, scaling, sweep
+        W, H, B, n_iso, planes = wl["W"], wl["H"], wl["B"], wl["n_iso"], wl["planes"]
+        self.seed = fic_amd.synth.SEEDS[wl["seed"]]
+        first = env.rank * planes if scaling == "weak" else 0
+        seeds = [self.seed + 3 * (first + p) for p in range(planes)]
+        self.dist_kind = dist_kind
+        if dist_kind == "U":
+            # synthetic input, generated on the device: resident in HBM before any timing (same integers as synth.image_u)
+            self.dev_in = fic_amd.synth.images_u_torch(W, H, seeds, torch.device("cuda", env.local_rank))
+        else:
+            self.dev_in = torch.from_numpy(np.stack([self.make_image(s) for s in seeds])).cuda()
+        self.cores = []
+        for _ in range(ncontexts):
+            if scaling == "strong":
+                enc = fic_amd.ShardedEncoder(W, H, B, None, n_iso, planes, env.local_rank)
+                c_, self.spans = enc.enc, enc.spans
+            else:
+                c_ = fic_amd.Encoder(W, H, B, None, n_iso, planes, env.local_rank)
+                self.spans = [(0, c_.n_ranges)] * env.world
+            c_.set_gray(self.dev_in)
+            c_.set_option("time_sweep", 1)
+            if chunks:
+                c_.set_option("chunks", chunks)
+            if sweep:
+                c_.set_option("sweep", sweep)
+            self.cores.append(c_)
+        self.core = self.cores[0]
+        self.begin, self.count = self.spans[env.rank]
+        # The sweeps run on compute streams of their own; the codebook gather of step k runs on torch's current stream (where
+        # the nccl backend orders its collectives) and overlaps with the sweep of step k+1.
+        self.computes = [torch.cuda.Stream() for _ in self.cores]
+        self.records = [c_.records_device() for c_ in self.cores]      # [planes, N_r, 6] int32 per context, written by its encodes
+        self.nbuf = 2
+        self.stage = [None] * self.nbuf      # copies of this rank's span where it is not contiguous in `records`
+        self.staged = [None] * self.nbuf
+        self.gathered = [None] * self.nbuf
+        self.step_no = 0
+        self.depth = 1
+        self.Nr, self.Nd = self.core.n_ranges, self.core.n_domains
+        self.ranges_per_step_rank = self.count * planes
+        self.ranges_per_step_total = self.Nr * planes * (env.world if scaling == "weak" else 1)
+
+    def make_image(self, s, w=None, h=None):
+        fic_amd, np = self.env.fic_amd, self.env.np
+        w, h = w or self.wl["W"], h or self.wl["H"]
+        if self.dist_kind == "U":
+            return fic_amd.synth.image_u(w, h, s)
+        if self.dist_kind == "S":
+            return fic_amd.synth.image_s(w, h, s)
+        base = np.load(os.path.join(ROOT, "tests", "golden", "lena_grey_256.npy"))
+        t = np.tile(base, ((h + 511) // 256 + 1, (w + 511) // 256 + 1))
+        oy, ox = (s * 7) % 256, (s * 13) % 256
+        return np.ascontiguousarray(t[oy:oy + h, ox:ox + w])
+
+    def set_option(self, name, value):
+        for c_ in self.cores:
+            c_.set_option(name, value)
+
+    def setup(self):
+        """Not a warm-up step: the first encode of a context allocates its fragment / queue buffers and makes the runtime load
+        the code object (8 ms against 2 ms per step).  Done once per context before the W warm-up steps so that `--warmup 0`
+        still times steady-state steps; no gather, nothing timed."""
+        for c_, st_ in zip(self.cores, self.computes):
+            c_.encode(self.begin, self.count, st_)
+        self.env.torch.cuda.synchronize()
+        self.sweep_times()
+
+    def step(self):
+        torch, env = self.env.torch, self.env
+        depth = self.depth
+        k = self.step_no % self.nbuf
+        ci = self.step_no % depth
+        self.step_no += 1
+        c_, compute = self.cores[ci], self.computes[ci]
+        if env.world == 1:
+            c_.encode(self.begin, self.count, compute)
+            return
+        with torch.cuda.stream(compute):
+            if self.gathered[k] is not None:
+                compute.wait_event(self.gathered[k])      # the gather that last read this buffer / context has finished
+            c_.encode(self.begin, self.count, compute)
+            src = self.records[ci][:, self.begin:self.begin + self.count]
+            if depth == self.nbuf and src.is_contiguous():
+                self.stage[k] = src                       # the context's own records: rewritten only by its next encode
+            else:
+                self.stage[k] = src.clone() if self.stage[k] is None or self.stage[k].data_ptr() == src.data_ptr() else self.stage[k].copy_(src)
+            self.staged[k] = torch.cuda.Event()
+            self.staged[k].record(compute)
+        cur = torch.cuda.current_stream()
+        cur.wait_event(self.staged[k])
+        rec = self.stage[k] if env.backend == "nccl" else self.stage[k].cpu()
+        env.fic_amd.gather_records(rec, self.spans, None, 0)
+        self.gathered[k] = torch.cuda.Event()
+        self.gathered[k].record(cur)
+
+    def sweep_times(self, reset=True):
+        ms = n = 0
+        for c_ in self.cores:                             # contexts that did not run report (0, 0)
+            m_, n_ = c_.sweep_time(reset=reset)
+            ms, n = ms + m_, n + n_
+        return ms, n
+
+    def timed(self, nsteps):
+        """EXACTLY nsteps steps between barrier + synchronize on both sides; returns (seconds on this rank, summed HIP-event
+        duration of the sweep launches, their number)."""
+        torch = self.env.torch
+        torch.cuda.synchronize()
+        self.sweep_times()
+        self.env.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(nsteps):
+            self.step()
+        torch.cuda.synchronize()
+        self.env.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        ms, n = self.sweep_times()
+        return dt, ms, n
+
+    def verify(self):
+        """After (and outside) the timed region: this rank's span re-encoded into a second context by the VALU-only sweep
+        (k_sweep_d4 / k_sweep_fast: another kernel family, exact integer covariances on the vector ALUs), and the 24-byte
+        codebook records compared on the device with what the timed kernel left behind."""
+        torch, fic_amd, wl = self.env.torch, self.env.fic_amd, self.wl
+        torch.cuda.synchronize()
+        mine = self.records[0][:, self.begin:self.begin + self.count].clone()
+        chk = fic_amd.Encoder(wl["W"], wl["H"], wl["B"], None, wl["n_iso"], wl["planes"], self.env.local_rank)
+        try:
+            valu = 5 if (wl["B"] == 8 and wl["n_iso"] == 8) else 2
+            chk.set_option("sweep", valu)
+            chk.set_gray(self.dev_in)
+            chk.encode(self.begin, self.count, self.computes[0])
+            chk.sync()
+            other = chk.records_device()[:, self.begin:self.begin + self.count]
+            same = bool(torch.equal(mine, other))
+            kind = chk.info()["sweep_kind"]
+            if not same:                      # say where: the line only carries true / false
+                bad = (mine != other).any(dim=-1).nonzero()
+                p0, r0 = int(bad[0][0]), int(bad[0][1])
+                print(f"bench.py rank {self.env.rank}: verify: {bad.shape[0]} of {mine.shape[0] * mine.shape[1]} records differ "
+                      f"(span {self.begin}+{self.count}); first: plane {p0} range {self.begin + r0}: timed kernel "
+                      f"{mine[p0, r0].tolist()} vs {kernel_name(kind, wl['B'], wl['n_iso'])[0]} {other[p0, r0].tolist()}", file=sys.stderr, flush=True)
+        finally:
+            chk.close()
+        ok = bool(self.env.min_over_ranks(1.0 if same else 0.0) > 0.5)
+        return {"ok": ok, "against": kernel_name(kind, wl["B"], wl["n_iso"])[0], "records_compared_per_rank": int(mine.shape[0] * mine.shape[1]),
+                "how": "after the timed region: the same span re-encoded by the VALU-only sweep into a second context; "
+                       "24-byte records (index, a bits, b bits, isometry, quantised s, o) compared on the device, all ranks"}
+
+    def close(self):
+        self.env.torch.cuda.synchronize()
+        for c_ in self.cores:
+            c_.close()
+        self.cores = []
+        self.dev_in = None
+        self.records = self.stage = None
+
+
+def roofline_blocks(args, run, info, avg_ms, sweep_n, clock_ghz):
+    """`roofline` (+ the logical-HBM block) of the sweep launches of one Run."""
+    env, wl = run.env, run.wl
+    B, n_iso, planes = wl["B"], wl["n_iso"], wl["planes"]
+    n, Nd = B * B, run.Nd
+    kind = info["sweep_kind"]
+    kname, operand = kernel_name(kind, B, n_iso, info["chunks"])
+    pair_evals = float(run.ranges_per_step_rank) * Nd * n_iso
+    # SURVEY 8(d)'s byte model: n+8 bytes per (range, domain) pair, one pool read per range block
+    alg_bytes = float(run.ranges_per_step_rank) * Nd * (n + 8)
+    rppr = env.fic_amd.capi.lib().fic_sweep_ranges_per_pool_read(kind, B, n_iso)
+    hbm_logical = {"bound": "hbm (logical)", "achieved": alg_bytes / (avg_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                   "frac": alg_bytes / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": alg_bytes,
+                   "ranges_per_pool_read": rppr or None,
+                   "note": "SURVEY 8(d): ranges x N_d x (n+8) bytes per launch.  NOT the bound of this kernel: a wave keeps its "
+                           "range tile in registers and reads a pool block once for all of it (`ranges_per_pool_read` range blocks per "
+                           "wave, from fic_sweep_ranges_per_pool_read; the waves of a workgroup share the load through L1/L2), so the "
+                           "physical traffic is `traffic` and the sweep is compute-bound (roofline)"}
+    traffic, traffic_note = None, "no PMC pass recorded for this kernel/workload on this source tree (tools/gpu_traffic.sh writes profiles/traffic.json)"
+    try:   # HBM-side bytes per sweep launch from a rocprofv3 --pmc side pass of this same command (profiles/traffic.json)
+        tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+        ent = tj.get(f"{args.workload}:planes={planes}:n_iso={n_iso}:kernel={kname}:gpus={env.world}")
+        if ent and ent.get("csrc_hash") == csrc_hash():
+            traffic, traffic_note = ent["bytes_per_launch"], ent["how"]
+        elif ent:
+            traffic_note = f"stale: profiles/traffic.json was measured on csrc {ent.get('csrc_hash')}, this tree is {csrc_hash()}"
+    except (OSError, ValueError, KeyError):
+        pass
+    if operand is not None:
+        # matrix-core sweeps: algorithmic work = 2n flop per pair evaluation (SURVEY 8d: n MACs per pair)
+        peak = MFMA_PEAK_TFLOPS[operand]
+        ops = pair_evals * 2.0 * n
+        # k_sweep_q's folded mode (8 isometries at B = 8 / 16) gets the 8 inner products of a (range, domain) pair from
+        # 4 even + 4 odd rows of K = n/2: half the matrix instructions of the algorithmic count
+        executed = ops * (0.5 if (kind == 6 and n_iso == 8 and B >= 8) else 1.0)
+        roofline = {"bound": "mfma", "achieved": ops / (avg_ms * 1e-3) / 1e12, "peak": peak,
+                    "unit": "TFLOP/s" if operand != "i8" else "TOP/s", "frac": ops / (avg_ms * 1e-3) / 1e12 / peak,
+                    "executed_frac": executed / (avg_ms * 1e-3) / 1e12 / peak,
+                    "traffic": traffic, "traffic_note": traffic_note, "kernel": kname, "operands": operand,
+                    "avg_launch_ms": avg_ms, "launches": sweep_n, "algorithmic_flop_per_launch": ops,
+                    "executed_flop_per_launch": executed, "matrix_pipe_frac": executed / (avg_ms * 1e-3) / 1e12 / peak,
+                    "clock_ghz": clock_ghz, "peak_clock_ghz": PEAK_CLOCK_GHZ,
+                    "matrix_pipe_frac_at_clock": executed / (avg_ms * 1e-3) / 1e12 / (peak * clock_ghz / PEAK_CLOCK_GHZ) if clock_ghz else None,
+                    "note": "achieved / frac: ALGORITHMIC flop = range blocks x N_d x n_iso x 2n per launch (SURVEY 8d: n MACs per "
+                            "pair evaluation) over the HIP-event duration of the launch on the sweep's stream, inside the timed "
+                            "region.  executed_frac (= matrix_pipe_frac): what the matrix cores really issue -- the folded 8-isometry "
+                            "form needs half the MACs (DESIGN.md 4.1), so frac can be 2x executed_frac and is NOT a pipe utilisation; "
+                            "executed_frac is the utilisation against the 2.4 GHz peak; clock_ghz is what the chip held under this kernel "
+                            "(shader-clock cycles / 100 MHz ticks of its own waves, a separate pass outside the timed region) and "
+                            "matrix_pipe_frac_at_clock the matrix-pipe utilisation at that clock"}
+    else:
+        # VALU instructions per pair evaluation of the sweep kernel (static count from the ISA):
+        # k_sweep_fast: n/4 v_dot4 per pair evaluation, plus per (range, domain): 1 iso -> 5; 8 iso -> 15, shared by 8
+        # k_sweep_d4: (n + n/2) / 2 v_dot2c + 37 other VALU per (range, domain), shared by the 8 copies (ISA count at B = 8)
+        vpe = ((n + n // 2) / 2 + 37.0) / 8.0 if kind == 5 else n / 4 + (15.0 / 8.0 if n_iso == 8 else 5.0)
+        ach = pair_evals * vpe / 64.0 / (avg_ms * 1e-3)
+        roofline = {"bound": "valu", "achieved": ach / 1e9, "peak": VALU_WAVE_INSTR_PEAK / 1e9, "unit": "G wave-instr/s",
+                    "frac": ach / VALU_WAVE_INSTR_PEAK, "traffic": traffic, "traffic_note": traffic_note, "kernel": kname,
+                    "avg_launch_ms": avg_ms, "launches": sweep_n, "valu_instr_per_pair_eval": vpe,
+                    "note": "peak = 1 wave64 VALU instruction / 4 cycles / SIMD x 1024 SIMDs x 2.4 GHz, the measured issue rate "
+                            "of v_dot4_u32_u8 / v_dot2c_i32_i16 (profiles/r01_valu_issue_rate_microbench.txt)"}
+    return roofline, hbm_logical, pair_evals
+
+
+def measure_clock(run, nsteps):
+    """The clock the chip holds under k_sweep_q, from the kernel's own counters (shader-clock cycles over 100 MHz ticks of a
+    sample of its waves).  Dense MFMA work is power-limited well below the 2.4 GHz the peak figures assume."""
+    core = run.core
+    core.set_option("sweep_stats", 1)
+    for _ in range(nsteps):
+        core.encode(run.begin, run.count, run.computes[0])
+    st = core.sweep_stats()
+    core.set_option("sweep_stats", 0)
+    return st
+
+
+def extra_block(env, args, name, scaling, steps):
+    """A few timed steps of another BASELINE configuration through the same Run (after the headline, outside its timed
+    region): ms per encode, matches/s, the kernel and its roofline fractions, and the post-run codebook check."""
+    wl = dict(WORKLOADS[name])
+    if args.extra_size and wl["W"] > args.extra_size:          # tests only
+        wl["W"] = wl["H"] = args.extra_size
+        wl["desc"] += f" [shrunk to {args.extra_size}x{args.extra_size} by --extra-size]"
+    env.watchdog.stage = f"extra block {name} ({scaling})"
+    run = Run(env, wl, scaling, 1, args.sweep, 0, "U")
+    try:
+        run.setup()
+        run.step()
+        dt, sweep_ms, sweep_n = run.timed(steps)
+        dt = env.max_over_ranks(dt)
+        per_rank = env.gather_floats(sweep_ms / max(sweep_n, 1))
+        info = run.core.info()
+        ver = None if args.no_verify else run.verify()
+        out = None
+        if env.rank == 0:
+            avg_ms = sweep_ms / max(sweep_n, 1)
+            roofline, _, pair_evals = roofline_blocks(args, run, info, avg_ms, sweep_n, None)
+            out = {"workload": wl["desc"], "scaling": scaling, "n_gpus": env.world, "steps": steps,
+                   "ms_per_encode": dt / steps * 1e3, "value": run.ranges_per_step_total * steps / dt, "unit": "range-block matches/s",
+                   "kernel": roofline["kernel"], "avg_launch_ms": avg_ms, "per_rank_sweep_ms": per_rank, "pool_chunks": info["chunks"],
+                   "pair_evals_per_s": pair_evals / (avg_ms * 1e-3) if avg_ms > 0 else None,
+                   "roofline": {k: roofline.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "executed_frac")},
+                   "verified": ver["ok"] if ver else None, "verified_against": ver["against"] if ver else None,
+                   "N_r": run.Nr, "N_d": run.Nd, "ranges_per_rank": run.count}
+        return out
+    finally:
+        run.close()
 
 
 def main():
@@ -245,6 +616,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    watchdog = Watchdog(rank, bench_timeout_s())
     if args.probe:
         sys.exit(probe(args, world, rank))
 
@@ -279,216 +651,52 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist
+        from datetime import timedelta
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        watchdog.stage = f"init_process_group({backend})"
+        # a rendezvous that does not complete in two minutes will not complete: fail instead of hanging the job
         if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank),
+                                    timeout=timedelta(seconds=120))
         else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
-
-    def barrier():
-        if dist:
-            if backend == "nccl":
-                dist.barrier(device_ids=[local_rank])
-            else:
-                dist.barrier()
+            dist.init_process_group(backend, rank=rank, world_size=world, timeout=timedelta(seconds=120))
+    env = Env(args, world, rank, local_rank, backend, dist, fic_amd, torch, np, watchdog)
 
     W, H, B, n_iso, planes = wl["W"], wl["H"], wl["B"], wl["n_iso"], wl["planes"]
-    seed = fic_amd.synth.SEEDS[wl["seed"]]
-    # synthetic input, generated once and uploaded: resident in HBM before any timing
-    def make_image(s, w=W, h=H):
-        if args.dist == "U":
-            return fic_amd.synth.image_u(w, h, s)
-        if args.dist == "S":
-            return fic_amd.synth.image_s(w, h, s)
-        base = np.load(os.path.join(ROOT, "tests", "golden", "lena_grey_256.npy"))
-        t = np.tile(base, ((h + 511) // 256 + 1, (w + 511) // 256 + 1))
-        oy, ox = (s * 7) % 256, (s * 13) % 256
-        return np.ascontiguousarray(t[oy:oy + h, ox:ox + w])
-
-    if scaling == "weak":
-        imgs = np.stack([make_image(seed + 3 * (rank * planes + p)) for p in range(planes)])
-    else:
-        imgs = np.stack([make_image(seed + 3 * p) for p in range(planes)])
-    dev_in = torch.from_numpy(imgs).cuda()
-
     # `--pipeline 2`: two contexts on two streams take the steps alternately, so the pool build / range prep of step k+1 and
     # the ragged tail of sweep k overlap on the chip (every step still does all of its work inside the timed region).  The
     # headline run keeps depth 1: with two sweeps sharing the chip a launch's HIP-event duration is no longer the time the
     # kernel needs, and `roofline` must come from the same timed region as `value`.  N = 1 reports depth 2 beside it.
     depth = max(1, min(2, args.pipeline))
     want_pipelined_leg = world == 1 and not args.no_alt and depth == 1
-    cores = []
-    for _ in range(2 if want_pipelined_leg else depth):
-        if scaling == "strong":
-            enc = fic_amd.ShardedEncoder(W, H, B, None, n_iso, planes, local_rank)
-            c_, spans = enc.enc, enc.spans
-        else:
-            c_ = fic_amd.Encoder(W, H, B, None, n_iso, planes, local_rank)
-            spans = [(0, c_.n_ranges)] * world
-        c_.set_gray(dev_in)
-        c_.set_option("time_sweep", 1)
-        if args.chunks:
-            c_.set_option("chunks", args.chunks)
-        if args.sweep:
-            c_.set_option("sweep", args.sweep)
-        cores.append(c_)
-    core = cores[0]
-    begin, count = spans[rank]
-    # The sweeps run on compute streams of their own; the codebook gather of step k runs on torch's current stream (where
-    # the nccl backend orders its collectives) and overlaps with the sweep of step k+1.
-    computes = [torch.cuda.Stream() for _ in cores]
-    records = [c_.records_device() for c_ in cores]       # [planes, N_r, 6] int32 per context, written by its encodes
-    nbuf = 2
-    stage = [None] * nbuf                                 # copies of this rank's span where it is not contiguous in `records`
-    staged = [None] * nbuf
-    gathered = [None] * nbuf
-    step_no = [0]
-    active_depth = [depth]
-
-    def step():
-        depth = active_depth[0]
-        k = step_no[0] % nbuf
-        ci = step_no[0] % depth
-        step_no[0] += 1
-        c_, compute = cores[ci], computes[ci]
-        if world == 1:
-            c_.encode(begin, count, compute)
-            return
-        with torch.cuda.stream(compute):
-            if gathered[k] is not None:
-                compute.wait_event(gathered[k])           # the gather that last read this buffer / context has finished
-            c_.encode(begin, count, compute)
-            src = records[ci][:, begin:begin + count]
-            if depth == nbuf and src.is_contiguous():
-                stage[k] = src                            # the context's own records: rewritten only by its next encode
-            else:
-                stage[k] = src.clone() if stage[k] is None or stage[k].data_ptr() == src.data_ptr() else stage[k].copy_(src)
-            staged[k] = torch.cuda.Event()
-            staged[k].record(compute)
-        cur = torch.cuda.current_stream()
-        cur.wait_event(staged[k])
-        rec = stage[k] if backend == "nccl" else stage[k].cpu()
-        fic_amd.gather_records(rec, spans, None, 0)
-        gathered[k] = torch.cuda.Event()
-        gathered[k].record(cur)
-
-    def sweep_times(reset=True):
-        ms = n = 0
-        for c_ in cores:                                  # contexts that did not run report (0, 0)
-            m_, n_ = c_.sweep_time(reset=reset)
-            ms, n = ms + m_, n + n_
-        return ms, n
-
-    def timed(nsteps):
-        torch.cuda.synchronize()
-        sweep_times()
-        barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(nsteps):
-            step()
-        torch.cuda.synchronize()
-        barrier()
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        ms, n = sweep_times()
-        return dt, ms, n
-
-    # Set-up, not a warm-up step: the first encode of a context allocates its fragment / queue buffers and makes the runtime load
-    # the code object (8 ms against 2 ms per step).  Done once per context before the W warm-up steps so that `--warmup 0`
-    # still times steady-state steps; no gather, nothing timed.
-    for c_, st_ in zip(cores, computes):
-        c_.encode(begin, count, st_)
-    torch.cuda.synchronize()
-    sweep_times()
+    watchdog.stage = "headline: set-up"
+    run = Run(env, wl, scaling, 2 if want_pipelined_leg else depth, args.sweep, args.chunks, args.dist)
+    run.depth = depth
+    run.setup()
+    watchdog.stage = "headline: warm-up + timed steps"
     for _ in range(max(args.warmup, depth) if args.warmup else 0):
-        step()
-    dt, sweep_ms, sweep_n = timed(args.steps)
-    per_rank_sweep_ms = [sweep_ms / max(sweep_n, 1)]
+        run.step()
+    dt, sweep_ms, sweep_n = run.timed(args.steps)
+    dt = env.max_over_ranks(dt)
+    per_rank_sweep_ms = env.gather_floats(sweep_ms / max(sweep_n, 1))
     rccl_ranks = None
     if dist:
-        dev = "cuda" if backend == "nccl" else "cpu"
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-        mine = torch.tensor([sweep_ms / max(sweep_n, 1)], dtype=torch.float64, device=dev)
-        allms = [torch.zeros_like(mine) for _ in range(world)]
-        dist.all_gather(allms, mine)
-        per_rank_sweep_ms = [float(x.item()) for x in allms]
         rccl_ranks = dist.get_world_size() if backend == "nccl" else 0
+    info = run.core.info()
+    watchdog.stage = "headline: codebook check"
+    verified = None if args.no_verify else run.verify()
 
-    Nr, Nd, n = core.n_ranges, core.n_domains, B * B
-    ranges_per_step_rank = count * planes
-    total_ranges = Nr * planes * (world if scaling == "weak" else 1) * args.steps
+    total_ranges = run.ranges_per_step_total * args.steps
     value = total_ranges / dt
-    info = core.info()
-
+    out = None
     if rank == 0:
         kind = info["sweep_kind"]
-        kname, operand = kernel_name(kind, B, n_iso, info["chunks"])
-        # The clock the chip holds under this sweep (outside the timed region): k_sweep_q's own counters, shader-clock cycles
-        # over 100 MHz ticks of a sample of its waves.  Dense MFMA work is power-limited well below the 2.4 GHz the peak
-        # figures assume, so the roofline block reports the fraction against both.
         clock_ghz = None
         if kind == 6:
-            core.set_option("sweep_stats", 1)
-            for _ in range(max(5, min(args.steps, 20))):
-                core.encode(begin, count, computes[0])
-            clock_ghz = core.sweep_stats()["clock_ghz"]
-            core.set_option("sweep_stats", 0)
+            clock_ghz = measure_clock(run, max(5, min(args.steps, 20)))["clock_ghz"]
         avg_ms = sweep_ms / max(sweep_n, 1)
-        pair_evals = float(ranges_per_step_rank) * Nd * n_iso
-        # SURVEY 8(d)'s byte model: n+8 bytes per (range, domain) pair, one pool read per range block
-        alg_bytes = float(ranges_per_step_rank) * Nd * (n + 8)
-        hbm_logical = {"bound": "hbm (logical)", "achieved": alg_bytes / (avg_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                       "frac": alg_bytes / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": alg_bytes,
-                       "ranges_per_pool_read": 64 if operand is None else 16,
-                       "note": "SURVEY 8(d): ranges x N_d x (n+8) bytes per launch.  NOT the bound of this kernel: a wave keeps its "
-                               "range tile in registers and reads a pool block once for all of it (`ranges_per_pool_read` per wave, "
-                               "four waves of a workgroup share the load through L1), so the physical traffic is `traffic` and the "
-                               "sweep is compute-bound (roofline)"}
-        traffic, traffic_note = None, "no PMC pass recorded for this kernel/workload on this source tree (tools/gpu_traffic.sh writes profiles/traffic.json)"
-        try:   # HBM-side bytes per sweep launch from a rocprofv3 --pmc side pass of this same command (profiles/traffic.json)
-            tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-            ent = tj.get(f"{args.workload}:planes={planes}:n_iso={n_iso}:kernel={kname}:gpus={world}")
-            if ent and ent.get("csrc_hash") == csrc_hash():
-                traffic, traffic_note = ent["bytes_per_launch"], ent["how"]
-            elif ent:
-                traffic_note = f"stale: profiles/traffic.json was measured on csrc {ent.get('csrc_hash')}, this tree is {csrc_hash()}"
-        except (OSError, ValueError, KeyError):
-            pass
-        if operand is not None:
-            # matrix-core sweeps: algorithmic work = 2n flop per pair evaluation (n MACs per pair)
-            peak = MFMA_PEAK_TFLOPS[operand]
-            ops = pair_evals * 2.0 * n
-            # k_sweep_q's folded mode (8 isometries at B = 8 / 16) gets the 8 inner products of a (range, domain) pair from
-            # 4 even + 4 odd rows of K = n/2: half the matrix instructions of the algorithmic count
-            executed = ops * (0.5 if (kind == 6 and n_iso == 8 and B >= 8) else 1.0)
-            roofline = {"bound": "mfma", "achieved": ops / (avg_ms * 1e-3) / 1e12, "peak": peak,
-                        "unit": "TFLOP/s" if operand != "i8" else "TOP/s", "frac": ops / (avg_ms * 1e-3) / 1e12 / peak,
-                        "traffic": traffic, "traffic_note": traffic_note, "kernel": kname, "operands": operand,
-                        "avg_launch_ms": avg_ms, "launches": sweep_n, "algorithmic_flop_per_launch": ops,
-                        "executed_flop_per_launch": executed, "matrix_pipe_frac": executed / (avg_ms * 1e-3) / 1e12 / peak,
-                        "clock_ghz": clock_ghz, "peak_clock_ghz": PEAK_CLOCK_GHZ,
-                        "matrix_pipe_frac_at_clock": executed / (avg_ms * 1e-3) / 1e12 / (peak * clock_ghz / PEAK_CLOCK_GHZ) if clock_ghz else None,
-                        "note": "achieved / frac: ALGORITHMIC flop = range blocks x N_d x n_iso x 2n per launch (SURVEY 8d: n MACs per "
-                                "pair evaluation) over the HIP-event duration of the launch on the sweep's stream, inside the timed "
-                                "region.  executed_flop / matrix_pipe_frac: what the matrix cores really issue -- the folded 8-isometry "
-                                "form needs half the MACs (DESIGN.md 4.5), so frac can exceed matrix_pipe_frac by 2x; matrix_pipe_frac "
-                                "is the utilisation against the 2.4 GHz peak; clock_ghz is what the chip held under this kernel "
-                                "(shader-clock cycles / 100 MHz ticks of its own waves, a separate pass outside the timed region) and "
-                                "matrix_pipe_frac_at_clock the matrix-pipe utilisation at that clock"}
-        else:
-            # VALU instructions per pair evaluation of the sweep kernel (static count from the ISA):
-            # k_sweep_fast: n/4 v_dot4 per pair evaluation, plus per (range, domain): 1 iso -> 5; 8 iso -> 15, shared by 8
-            # k_sweep_d4: (n + n/2) / 2 v_dot2c + 37 other VALU per (range, domain), shared by the 8 copies (ISA count at B = 8)
-            vpe = ((n + n // 2) / 2 + 37.0) / 8.0 if kind == 5 else n / 4 + (15.0 / 8.0 if n_iso == 8 else 5.0)
-            ach = pair_evals * vpe / 64.0 / (avg_ms * 1e-3)
-            roofline = {"bound": "valu", "achieved": ach / 1e9, "peak": VALU_WAVE_INSTR_PEAK / 1e9, "unit": "G wave-instr/s",
-                        "frac": ach / VALU_WAVE_INSTR_PEAK, "traffic": traffic, "traffic_note": traffic_note, "kernel": kname,
-                        "avg_launch_ms": avg_ms, "launches": sweep_n, "valu_instr_per_pair_eval": vpe,
-                        "note": "peak = 1 wave64 VALU instruction / 4 cycles / SIMD x 1024 SIMDs x 2.4 GHz, the measured issue rate "
-                                "of v_dot4_u32_u8 / v_dot2c_i32_i16 (profiles/r01_valu_issue_rate_microbench.txt)"}
+        roofline, hbm_logical, pair_evals = roofline_blocks(args, run, info, avg_ms, sweep_n, clock_ghz)
+        operand = roofline.get("operands")
         out = {
             "metric": "range-block matches/sec (8x8 R, 16x16 D, 8 iso)" if (B == 8 and n_iso == 8) else
                       f"range-block matches/sec ({B}x{B} R, {2 * B}x{2 * B} D, {n_iso} iso)",
@@ -503,56 +711,130 @@ def main():
                              None: "u8 pixels, v_dot4_u32_u8 / v_dot2c_i32_i16 -> exact i32 covariances, f32 prune test, f64/f32 Java epilogue"}[operand],
             "data": "synthetic",
             "config": {"workload": wl["desc"] if args.dist == "U" else wl["desc"].replace("synthetic grey U", f"grey {args.dist}"),
-                       "dist": args.dist, "image": f"{W}x{H}", "B": B, "n_iso": n_iso, "wK": core.wK,
+                       "dist": args.dist, "image": f"{W}x{H}", "B": B, "n_iso": n_iso, "wK": run.core.wK,
                        "planes_per_rank" if scaling == "weak" else "planes": planes,
-                       "N_r": Nr, "N_d": Nd, "pool_chunks": info["chunks"], "sweep_kind": kind, "pipeline_depth": depth,
+                       "N_r": run.Nr, "N_d": run.Nd, "pool_chunks": info["chunks"], "sweep_kind": kind, "pipeline_depth": depth,
                        "setup": "one untimed encode per context before the warm-up steps (buffer allocation, code object load)",
                        "parallelism": f"range/plane shards x{world}"},
             "pair_evals_per_s": pair_evals * sweep_n / (sweep_ms * 1e-3) if sweep_ms > 0 else None,
             "roofline": roofline,
             "roofline_hbm_logical": hbm_logical,
+            "verified": verified["ok"] if verified else None,
+            "verified_detail": verified,
             "rccl_ranks": rccl_ranks,
             "per_rank_sweep_ms": per_rank_sweep_ms,
             "csrc_hash": csrc_hash(),
         }
-        if world == 1 and not args.no_alt and operand is not None:
-            # north_star's literal design (VALU only, no MFMA) on the same workload and buffers: reported beside, never as `value`
-            for c_ in cores:
-                c_.set_option("sweep", 5 if (B == 8 and n_iso == 8) else 2)
-            for _ in range(max(args.warmup, depth)):
-                step()
-            dtv, msv, nv = timed(args.steps)
-            iv = core.info()
-            for c_ in cores:
-                c_.set_option("sweep", args.sweep)
-            out["valu_only"] = {"how": "fic_ctx_set_option(ctx, \"sweep\", 5 or 2) / FIC_SWEEP=5", "kernel": kernel_name(iv["sweep_kind"], B, n_iso)[0],
-                                "value": total_ranges / dtv, "unit": "range-block matches/s", "ms_per_step": dtv / args.steps * 1e3,
-                                "avg_launch_ms": msv / max(nv, 1), "default_speedup": dtv / dt,
-                                "note": "bit-identical codebooks (tests/test_gpu_mfma.py, test_gpu_fullsize.py); this is the sweep "
-                                        "north_star describes (no MFMA).  Its premise -- reduction/bandwidth-bound -- does not hold: "
-                                        "profiles/r01z_cfg2_default_pmc_summary.txt shows 0.7 % of HBM peak and VALU busy 93.5 %, so the "
-                                        "library default is the matrix-core sweep"}
-        if want_pipelined_leg:
-            active_depth[0] = 2
-            for _ in range(max(args.warmup, 2)):
-                step()
-            dtp, msp, npl = timed(args.steps)
-            active_depth[0] = depth
-            out["pipelined"] = {"how": "bench.py --pipeline 2: two fic_ctx on two streams take the steps alternately", "depth": 2,
-                                "value": total_ranges / dtp, "unit": "range-block matches/s", "ms_per_step": dtp / args.steps * 1e3,
-                                "avg_launch_ms": msp / max(npl, 1),
-                                "note": "same work per step; the prep kernels of step k+1 fill the ragged tail of sweep k, so the "
-                                        "launches overlap and avg_launch_ms is no longer the time one sweep needs (hence not `value`)"}
-        if world == 1 and not args.no_alt and args.workload == "cfg2" and not (args.size or args.block or args.planes or args.n_iso):
-            out["single_image"] = single_image(fic_amd, torch, make_image(seed), B, n_iso, local_rank, args.sweep)
-        if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(wl, imgs[0], args.cpu_budget)
+
+    # ---- legs beside the headline (never `value`) ------------------------------------------------------------------
+    if world == 1 and not args.no_alt and args.sustain > 0:
+        watchdog.stage = "sustained"
+        out["sustained"] = sustained(run, args.sustain, value)
+    if world == 1 and not args.no_alt and out["roofline"].get("operands") is not None:
+        # north_star's literal design (VALU only, no MFMA) on the same workload and buffers: reported beside, never as `value`
+        watchdog.stage = "valu_only"
+        run.set_option("sweep", 5 if (B == 8 and n_iso == 8) else 2)
+        for _ in range(max(args.warmup, depth)):
+            run.step()
+        dtv, msv, nv = run.timed(args.steps)
+        iv = run.core.info()
+        run.set_option("sweep", args.sweep)
+        out["valu_only"] = {"how": "fic_ctx_set_option(ctx, \"sweep\", 5 or 2) / FIC_SWEEP=5", "kernel": kernel_name(iv["sweep_kind"], B, n_iso)[0],
+                            "value": total_ranges / dtv, "unit": "range-block matches/s", "ms_per_step": dtv / args.steps * 1e3,
+                            "avg_launch_ms": msv / max(nv, 1), "default_speedup": dtv / dt,
+                            "note": "bit-identical codebooks (tests/test_gpu_bench_geometry.py, test_gpu_fullsize.py, `verified`); this is the "
+                                    "sweep north_star describes (no MFMA).  Its premise -- reduction/bandwidth-bound -- does not hold: "
+                                    "profiles/r01z_cfg2_default_pmc_summary.txt shows 0.7 % of HBM peak and VALU busy 93.5 %, so the "
+                                    "library default is the matrix-core sweep"}
+    if want_pipelined_leg:
+        watchdog.stage = "pipelined"
+        run.depth = 2
+        for _ in range(max(args.warmup, 2)):
+            run.step()
+        dtp, msp, npl = run.timed(args.steps)
+        run.depth = depth
+        out["pipelined"] = {"how": "bench.py --pipeline 2: two fic_ctx on two streams take the steps alternately", "depth": 2,
+                            "value": total_ranges / dtp, "unit": "range-block matches/s", "ms_per_step": dtp / args.steps * 1e3,
+                            "avg_launch_ms": msp / max(npl, 1),
+                            "note": "same work per step; the prep kernels of step k+1 fill the ragged tail of sweep k, so the "
+                                    "launches overlap and avg_launch_ms is no longer the time one sweep needs (hence not `value`)"}
+    plain = args.workload == "cfg2" and not (args.size or args.block or args.planes or args.n_iso)
+    if world == 1 and not args.no_alt and plain:
+        watchdog.stage = "single_image"
+        out["single_image"] = single_image(fic_amd, torch, run.make_image(run.seed), B, n_iso, local_rank, args.sweep)
+    img0 = run.dev_in[0].cpu().numpy() if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None
+    run.close()
+
+    # ---- the other BASELINE configurations and the strong-scaling point -------------------------------------------------
+    if plain and not args.no_extra and not (world == 1 and args.no_alt):
+        strong = None
+        if world == 1:
+            others = {}
+            for name in OTHER_CONFIGS:
+                others[name] = extra_block(env, args, name, WORKLOADS[name]["scaling"], args.extra_steps)
+            out["other_configs"] = others
+            strong = dict(others["cfg4"], note="N = 1: the same run as other_configs.cfg4")
+        else:
+            strong = extra_block(env, args, "cfg4", "strong", args.extra_steps)
+        if rank == 0:
+            strong["what"] = ("BASELINE config 4 (one 4096x4096 image, B=8, full search, 8 isometries): range blocks sharded over the "
+                              "ranks, pool replicated, one gather of 24-byte records per step -- north_star's strong-scaling point "
+                              "(>= 6x at 8 GPUs = this block's `value` at N=8 over its `value` at N=1)")
+            out["strong_cfg4"] = strong
+
+    if rank == 0:
+        watchdog.stage = "cpu_baseline"
+        if img0 is not None:
+            out["cpu_baseline"] = cpu_baseline(wl, img0, args.cpu_budget)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
-    barrier()
+    watchdog.stage = "final barrier"
+    env.barrier()
     if dist:
         dist.destroy_process_group()
+    watchdog.cancel()
+    if verified is not None and not verified["ok"]:
+        sys.exit("bench.py: the codebook of the timed configuration differs from the VALU-only sweep's (verified = false)")
+
+
+def sustained(run, seconds, headline_value):
+    """The same step loop for >= `seconds` of wall time (not --steps): what the chip sustains once its clock has settled
+    under the load (a 40 ms timed region on a power-limited kernel starts from a cool chip).  Then, without a pause, the
+    loop goes on with the kernel's own clock counters switched on."""
+    torch = run.env.torch
+    batch = 100
+    torch.cuda.synchronize()
+    run.sweep_times()
+    t0 = time.perf_counter()
+    steps = 0
+    while True:
+        for _ in range(batch):
+            run.step()
+        steps += batch
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if dt >= seconds:
+            break
+    ms, n = run.sweep_times()
+    clock = None
+    kind = run.core.info()["sweep_kind"]
+    if kind == 6:
+        t1 = time.perf_counter()
+        run.core.set_option("sweep_stats", 1)
+        nclk = 0
+        while time.perf_counter() - t1 < max(0.25 * seconds, 0.2):
+            for _ in range(batch):
+                run.core.encode(run.begin, run.count, run.computes[0])
+            nclk += batch
+            torch.cuda.synchronize()
+        clock = run.core.sweep_stats()["clock_ghz"]
+        run.core.set_option("sweep_stats", 0)
+    v = run.ranges_per_step_total * steps / dt
+    return {"seconds": dt, "steps": steps, "value": v, "unit": "range-block matches/s", "ms_per_step": dt / steps * 1e3,
+            "avg_launch_ms": ms / max(n, 1), "clock_ghz": clock, "vs_timed_region": v / headline_value,
+            "note": "same step() as the headline, run back to back for >= --sustain seconds of wall time (host sync every 100 "
+                    "steps); clock_ghz: the in-kernel clock of k_sweep_q sampled while the loop simply continues"}
 
 
 def single_image(fic_amd, torch, img, B, n_iso, device, sweep, reps=200):

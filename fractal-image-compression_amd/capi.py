@@ -102,8 +102,10 @@ def lib():
         "fic_ctx_set_option": (C.c_int, [vp, C.c_char_p, C.c_int]),
         "fic_ctx_sweep_time": (C.c_int, [vp, C.POINTER(C.c_double), ip, C.c_int]),
         "fic_ctx_info": (C.c_int, [vp, ip]),
+        "fic_sweep_ranges_per_pool_read": (C.c_int, [C.c_int, C.c_int, C.c_int]),
         "fic_ctx_sweep_stats": (C.c_int, [vp, C.POINTER(C.c_uint64), C.c_int]),
         "fic_debug_rccl_selftest": (C.c_int, [C.c_int]),
+        "fic_debug_gather_fallbacks": (C.c_int, []),
         "fic_debug_float_sum": (C.c_int, [C.c_int, C.c_float, C.POINTER(C.c_uint32), C.c_int, f32p]),
         "fic_debug_decode_gray_run": (C.c_int, [u8p, C.c_int64, C.c_int, u8p, C.c_int64, f32p, ip, ip]),
         "fic_debug_sqrt_f64": (C.c_int, [C.c_int, C.c_uint32, C.c_uint32, C.POINTER(C.c_double)]),
@@ -168,18 +170,26 @@ def encode_gray_oneshot(gray, B, wK, n_iso=1, device=0):
     return r
 
 
-def encode_gray_multi(gray, B, wK, n_iso=1, n_gpus=1):
-    """fic_encode_gray_u8_multi: one synchronous call, range blocks sharded over the first n_gpus devices, RCCL gather in
-    the library (what the JNI host calls on a multi-GPU node)."""
-    g = np.ascontiguousarray(gray, np.uint8)
-    h, w = g.shape
+def encode_gray_multi(gray, B, wK, n_iso=1, n_gpus=1, width=None, height=None):
+    """fic_encode_gray_u8_multi / fic_encode_gray_argb_multi: one synchronous call, range blocks sharded over the first
+    n_gpus devices, RCCL gather in the library (what the JNI host calls on a multi-GPU node).  `gray`: uint8 [H, W], or --
+    with width and height given -- the int32 ARGB pixels of RasterImage.argb."""
+    if width is not None:
+        g = np.ascontiguousarray(gray, np.int32).reshape(-1)
+        w, h = int(width), int(height)
+        if g.size != w * h:
+            raise FicError(-3, "argb has the wrong number of pixels")
+        fn, p = lib().fic_encode_gray_argb_multi, ptr(g, C.c_int32)
+    else:
+        g = np.ascontiguousarray(gray, np.uint8)
+        h, w = g.shape
+        fn, p = lib().fic_encode_gray_u8_multi, ptr(g, C.c_uint8)
     Rw, Rh, Dw, Dh = geometry(w, h, B)
     nr = Rw * Rh
     r = {"idx_local": np.zeros(nr, np.int32), "a": np.zeros(nr, np.float32), "b": np.zeros(nr, np.float32),
          "iso": np.zeros(nr, np.int32), "qrows": np.zeros((nr, 3), np.int32)}
-    check(lib().fic_encode_gray_u8_multi(ptr(g, C.c_uint8), w, h, B, Dw if wK is None else wK, n_iso, n_gpus,
-                                         ptr(r["idx_local"], C.c_int32), ptr(r["a"], C.c_float), ptr(r["b"], C.c_float),
-                                         ptr(r["iso"], C.c_int32), ptr(r["qrows"], C.c_int32)))
+    check(fn(p, w, h, B, Dw if wK is None else wK, n_iso, n_gpus, ptr(r["idx_local"], C.c_int32), ptr(r["a"], C.c_float),
+             ptr(r["b"], C.c_float), ptr(r["iso"], C.c_int32), ptr(r["qrows"], C.c_int32)))
     return r
 
 

@@ -503,6 +503,10 @@ fic_ctx* fic_ctx_create(int device, int w, int h, int B, int wK, int n_iso, int 
         if (e == hipSuccess) e = hipMemset(c->b.pool_st, 0, P * g.Nd_pad * sizeof(FicDomStat));
         if (e == hipSuccess) e = hipMemset(c->b.pool_var, 0, P * g.Nd_pad * sizeof(uint32_t));
         if (e == hipSuccess) e = hipMemset(c->b.pool_s64, 0, P * g.Nd_pad * sizeof(double));
+        // hipMemset on device memory only ENQUEUES on the null stream; encodes run on the caller's stream, which may be
+        // non-blocking (torch's are): without this wait a first encode issued right away can be overtaken by the fill
+        // (seen with two processes sharing one GPU: bench.py's post-run check context, round 3)
+        if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
         if (e != hipSuccess) rc = fail(FIC_E_HIP, "hipMemset: %s", hipGetErrorString(e));
     }
     if (rc != FIC_OK) {
@@ -729,6 +733,7 @@ int fic_ctx_set_option(fic_ctx* c, const char* name, int value)
         if (value && !c->q_stats) {
             HIP_TRY(hipMalloc((void**)&c->q_stats, 8 * sizeof(unsigned long long)));
             HIP_TRY(hipMemset(c->q_stats, 0, 8 * sizeof(unsigned long long)));
+            HIP_TRY(hipStreamSynchronize(nullptr));            // the fill is only enqueued (null stream); sweeps run on other streams
         } else if (!value && c->q_stats) {
             HIP_TRY(hipStreamSynchronize(c->last_stream));
             (void)hipFree(c->q_stats);
@@ -761,7 +766,10 @@ int fic_ctx_sweep_stats(fic_ctx* c, uint64_t* out8, int reset)
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->last_stream));
     HIP_TRY(hipMemcpy(out8, c->q_stats, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost));
-    if (reset) HIP_TRY(hipMemset(c->q_stats, 0, 8 * sizeof(uint64_t)));
+    if (reset) {
+        HIP_TRY(hipMemset(c->q_stats, 0, 8 * sizeof(uint64_t)));
+        HIP_TRY(hipStreamSynchronize(nullptr));
+    }
     return FIC_OK;
 }
 
@@ -772,6 +780,18 @@ int fic_ctx_info(fic_ctx* c, int* out10)
     int v[10] = {g.Rw, g.Rh, g.Nr, g.Dw, g.Dh, g.Nd, g.NR, g.tiles, c->last_chunks, c->last_kind};
     memcpy(out10, v, sizeof(v));
     return FIC_OK;
+}
+
+int fic_sweep_ranges_per_pool_read(int kind, int B, int n_iso)
+{
+    if ((B != 4 && B != 8 && B != 16) || (n_iso != 1 && n_iso != 8)) return 0;
+    if (kind == 6) return fic_q_ctw_host(B) * 32 / fic_q_cols_per_range(B, n_iso);
+    if (kind == 2 || kind == 5) {
+        int NR = 1, NC = 1;
+        fic_fast_variant(B, n_iso, &NR, &NC);
+        return 64 * (kind == 5 ? 1 : NR);
+    }
+    return 0;
 }
 
 int fic_debug_sqrt_f64(int device, uint32_t first, uint32_t count, double* out)

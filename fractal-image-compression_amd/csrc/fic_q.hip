@@ -780,6 +780,7 @@ static bool q_launch(int NK, int mode, bool multi, dim3 grid, dim3 block, hipStr
     return true;
 }
 int fic_q_ct(int B) { return FIC_Q_WPG * fic_q_ctw(B * B / 16); }       // column tiles (x32 columns) per workgroup
+int fic_q_ctw_host(int B) { return fic_q_ctw(B * B / 16); }
 // 0: 1 isometry; 1: 8 isometries, one column per copy; 2: 8 isometries folded into 4 columns per range block
 int fic_q_mode(int B, int n_iso) { return n_iso == 1 ? 0 : (B == 4 ? 1 : 2); }
 int fic_q_cols_per_range(int B, int n_iso) { const int m = fic_q_mode(B, n_iso); return m == 0 ? 1 : (m == 1 ? 8 : 4); }

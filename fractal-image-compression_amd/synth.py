@@ -38,3 +38,27 @@ def image_s(w, h, seed):
 
 def image(kind, w, h, seed):
     return image_u(w, h, seed) if kind.upper() == "U" else image_s(w, h, seed)
+
+
+def images_u_torch(w, h, seeds, device="cuda"):
+    """The U images of `seeds` as one uint8 torch tensor [len(seeds), h, w], generated on `device` (the same integers as
+    image_u: SplitMix64 in wrapping int64 arithmetic with logical shifts).  bench.py builds its batches with this: the
+    numpy generator needs seconds per 16 M pixels on the host."""
+    import torch
+
+    def s64(c):                       # uint64 constant as the int64 with the same bits
+        return c - (1 << 64) if c >= (1 << 63) else c
+
+    def lsr(z, k):
+        return (z >> k) & ((1 << (64 - k)) - 1)
+
+    idx = torch.arange(w * h, dtype=torch.int64, device=device)
+    out = torch.empty((len(seeds), h, w), dtype=torch.uint8, device=device)
+    for i, seed in enumerate(seeds):
+        z = idx + s64(int(seed) & 0xFFFFFFFFFFFFFFFF)
+        z = z + s64(0x9E3779B97F4A7C15)
+        z = (z ^ lsr(z, 30)) * s64(0xBF58476D1CE4E5B9)
+        z = (z ^ lsr(z, 27)) * s64(0x94D049BB133111EB)
+        z = z ^ lsr(z, 31)
+        out[i] = lsr(z, 56).to(torch.uint8).view(h, w)
+    return out

@@ -228,6 +228,10 @@ FIC_API int fic_ctx_sweep_time(fic_ctx* ctx, double* total_ms, int* launches, in
 FIC_API int fic_ctx_sweep_stats(fic_ctx* ctx, uint64_t* out8, int reset);
 /* Geometry actually in use: out[0..9] = Rw, Rh, N_r, Dw, Dh, N_d, NR, tiles, chunks, sweep kind. */
 FIC_API int fic_ctx_info(fic_ctx* ctx, int* out10);
+/* Range blocks one wave of sweep `kind` keeps in registers, i.e. how many range blocks share one read of a pool block
+ * (the reuse factor between SURVEY 8(d)'s byte model and the physical traffic): k_sweep_q 32 / 128 (B = 8: 8 / 1
+ * isometries), 32 / 256 (B = 4), 16 / 64 (B = 16); the VALU sweeps 64 x NR.  0: not defined for that kind. */
+FIC_API int fic_sweep_ranges_per_pool_read(int kind, int B, int n_iso);
 
 /* Test hook: out[i] = sqrt((double)(first + i)) computed on the device exactly as the pool
  * kernel does for Domainblock.variance (FractalCompression.java:677,680 Math.sqrt). */
@@ -238,9 +242,14 @@ FIC_API int fic_debug_float_sum(int device, float carry, const uint32_t* vals, i
 /* Test hook: fic_decode_gray_run that also reports in seq_sums how many iterations took the sequential float sum. */
 FIC_API int fic_debug_decode_gray_run(const uint8_t* run, int64_t len, int device, uint8_t* gray_out, int64_t capacity,
                                       float* avg_error_io, int* iterations, int* seq_sums);
-/* Test hook: loads RCCL, creates one communicator per device 0..n-1 and (n >= 2) runs the codebook gather's grouped
- * send/recv pattern on dummy records, checking what arrives on device 0. */
+/* Test hook: loads RCCL, creates one communicator per device 0..|n|-1 and (|n| >= 2) runs the codebook gather's grouped
+ * send/recv pattern on dummy records, checking what arrives on device 0.  n < 0: the gather's ERROR path on |n| devices
+ * (a send to a peer that does not exist must fail, leave no group open and no communicator cached; the same pattern
+ * must then succeed on fresh communicators). */
 FIC_API int fic_debug_rccl_selftest(int n);
+/* Calls of fic_encode_gray_*_multi in this process that finished with peer copies after an RCCL failure (FIC_GATHER
+ * unset / "rccl": fall back; "rccl-only": return the error; "copy": peer copies only). */
+FIC_API int fic_debug_gather_fallbacks(void);
 /* Test hook: copies the pool of the last encode to the host: pix u8 [planes][N_d][n],
  * sum u32 [planes][N_d], var u32 [planes][N_d], scaled u8 [planes][h/2][w/2]. NULLs allowed. */
 FIC_API int fic_ctx_debug_pool_host(fic_ctx* ctx, uint8_t* pix, uint32_t* sum, uint32_t* var, uint8_t* scaled);

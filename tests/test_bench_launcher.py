@@ -7,6 +7,7 @@ import os
 import socket
 import subprocess
 import sys
+import time
 
 import pytest
 
@@ -69,3 +70,24 @@ def test_launch_ranks_environment_and_worst_exit_code():
     # a hung peer of a failed rank is stopped instead of waited for
     hang = "import os,sys,time; r=int(os.environ['RANK']); sys.exit(3) if r==0 else time.sleep(600)"
     assert bench.launch_ranks(2, [sys.executable, "-c", hang], env=_env()) == 3
+
+
+def test_a_rank_that_never_reaches_the_rendezvous_ends_the_launch_inside_the_deadline():
+    """ranks that hang in init_process_group / the first gather must not leave a silent job behind.  Rank 1
+    sleeps instead of joining; FIC_BENCH_TIMEOUT bounds the launcher (and every rank's own watchdog)."""
+    t0 = time.time()
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--probe", "--probe-hang-rank", "1"], capture_output=True, text=True,
+                       env=dict(_env(), FIC_BENCH_TIMEOUT="10"), timeout=200)
+    assert r.returncode != 0
+    assert time.time() - t0 < 90
+    assert "FIC_BENCH_TIMEOUT" in r.stderr
+
+
+def test_launch_ranks_deadline_names_the_live_ranks(capfd):
+    sys.path.insert(0, ROOT)
+    import bench
+    code = "import os,sys,time; time.sleep(600) if os.environ['RANK']=='1' else sys.exit(0)"
+    t0 = time.time()
+    assert bench.launch_ranks(2, [sys.executable, "-c", code], env=_env(), deadline_s=3.0) == 124
+    assert time.time() - t0 < 30
+    assert "ranks [1] of 2 still running" in capfd.readouterr().err

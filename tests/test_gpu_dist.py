@@ -96,6 +96,33 @@ def test_bench_self_launches_two_ranks():
     assert j["n_gpus"] == 2 and j["scaling"] == "strong" and j["value"] > 0
 
 
+def test_bench_default_line_carries_every_block():
+    """The default line (what the driver runs at N = 1): the headline plus `verified`, `sustained`, `other_configs`
+    (BASELINE configs 3, 4, 4 with 1 isometry, 5) and `strong_cfg4`.  The big images are shrunk for the test."""
+    j = _bench(["--steps", "2", "--warmup", "1", "--cpu-budget", "1", "--sustain", "0.3", "--extra-size", "512", "--extra-steps", "2"])
+    assert j["verified"] is True and j["verified_detail"]["against"] == "k_sweep_d4"
+    assert j["config"]["sweep_kind"] == 6 and j["roofline"]["kernel"] == "k_sweep_q<4, 2, false>"
+    assert 0 < j["roofline"]["executed_frac"] <= j["roofline"]["frac"]
+    assert j["roofline_hbm_logical"]["ranges_per_pool_read"] == 32
+    assert j["sustained"]["seconds"] >= 0.3 and j["sustained"]["value"] > 0 and j["sustained"]["clock_ghz"] > 0.5
+    assert set(j["other_configs"]) == {"cfg3", "cfg4", "cfg4iso1", "cfg5"}
+    for name, o in j["other_configs"].items():
+        assert o["verified"] is True and o["value"] > 0 and o["ms_per_encode"] > 0 and o["roofline"]["frac"] > 0, name
+    assert j["strong_cfg4"]["n_gpus"] == 1 and j["strong_cfg4"]["value"] == j["other_configs"]["cfg4"]["value"]
+    assert j["single_image"]["ms"] > 0 and j["valu_only"]["value"] > 0 and j["pipelined"]["value"] > 0 and j["cpu_baseline"]["value"] > 0
+
+
+def test_bench_two_ranks_default_line_has_the_strong_scaling_block():
+    """`python bench.py --gpus 2` with no workload flags (what the driver runs on the multi-GPU node): weak cfg2 headline and
+    the strong-scaling block, config 4's range blocks sharded over the two ranks through the same gather."""
+    j = _bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--extra-size", "512", "--extra-steps", "2"], {"FIC_BENCH_BACKEND": "gloo"})
+    assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["verified"] is True
+    s4 = j["strong_cfg4"]
+    assert s4["n_gpus"] == 2 and s4["scaling"] == "strong" and s4["verified"] is True and s4["value"] > 0
+    assert s4["ranges_per_rank"] * 2 == s4["N_r"] and len(s4["per_rank_sweep_ms"]) == 2
+    assert "other_configs" not in j
+
+
 NO_TORCH = r"""
 import sys, time, json
 sys.path.insert(0, {root!r})

@@ -66,6 +66,37 @@ def test_rccl_loads_and_creates_communicators():
     capi.release_cache()
 
 
+def test_rccl_gather_error_path_closes_the_group_and_drops_the_communicators():
+    """an error inside ncclGroupStart .. ncclGroupEnd must not leave the thread's group open or stale
+    communicators cached.  The library's own gather function is driven with a send RCCL must refuse; afterwards the same
+    pattern has to work on fresh communicators."""
+    n = min(capi.lib().fic_device_count(), 8)
+    capi.check(capi.lib().fic_debug_rccl_selftest(-n))
+    capi.check(capi.lib().fic_debug_rccl_selftest(n))
+    capi.release_cache()
+
+
+def test_multi_device_entry_with_argb_input_and_peer_copy_gather(fake8, oracle):
+    """ARGB input through the pinned staging copy (R channel, FC:596) and asynchronous per-device uploads; FIC_GATHER=copy."""
+    g = synth.image_s(256, 256, 77)
+    argb = oracle.gray_to_argb(g)
+    one = capi.encode_gray_oneshot(g, 8, None, 8)
+    old = os.environ.get("FIC_GATHER")
+    os.environ["FIC_GATHER"] = "copy"
+    try:
+        for n in (2, 5):
+            got = capi.encode_gray_multi(argb, 8, None, 8, n, width=256, height=256)
+            for k in ("idx_local", "iso", "qrows"):
+                assert (got[k] == one[k]).all(), (n, k)
+            assert same_f32(got["a"], one["a"]) and same_f32(got["b"], one["b"])
+    finally:
+        if old is None:
+            del os.environ["FIC_GATHER"]
+        else:
+            os.environ["FIC_GATHER"] = old
+    assert capi.lib().fic_debug_gather_fallbacks() == 0
+
+
 def test_cpp_driver_multi_device(tmp_path, oracle):
     """The compiled C++ driver (no Python, no torch in the process): n_gpus = 1 and k logical devices give the same .run bytes."""
     exe = os.path.join(ROOT, "tests", "cpp", "host_mirror_test")

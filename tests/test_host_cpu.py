@@ -243,3 +243,14 @@ def test_jni_shim_parses_against_a_stub_jni_h():
     java = open(os.path.join(root, "fractal-image-compression_amd", "java", "bvk_ss19", "FicNative.java")).read()
     for name in ("deviceCount", "encodeGray", "encodeGrayMulti", "encodeRgb", "decode"):
         assert f"native " in java and f" {name}(" in java and f"Java_bvk_1ss19_FicNative_{name}(" in code
+
+
+def test_device_side_synthetic_generator_equals_the_numpy_one():
+    """synth.images_u_torch (what bench.py fills HBM with) produces the integers of synth.image_u (SURVEY 8d's U)."""
+    import torch
+    from fic_amd import synth
+    seeds = [synth.SEEDS["cfg2"], synth.SEEDS["cfg5"] + 3 * 17 + 2, 0xFFFFFFFFFFFFFFF0, 7]
+    got = synth.images_u_torch(96, 64, seeds, "cpu").numpy()
+    for i, s in enumerate(seeds):
+        assert (got[i] == synth.image_u(96, 64, s)).all()
+    assert got.dtype == np.uint8 and got.shape == (4, 64, 96)
