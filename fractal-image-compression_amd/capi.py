@@ -55,11 +55,12 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(SO_PATH):
-        raise FicError(-5, f"{SO_PATH} is missing: build it with __graft_entry__.build() "
+    so = os.environ.get("FIC_HIP_SO") or SO_PATH          # FIC_HIP_SO: another build of the same library (A/B runs of kernel variants)
+    if not os.path.exists(so):
+        raise FicError(-5, f"{so} is missing: build it with __graft_entry__.build() "
                            "(hipcc --offload-arch=gfx950); there is no fallback path")
     _torch_first()
-    L = C.CDLL(SO_PATH)
+    L = C.CDLL(so)
     vp, ip = C.c_void_p, C.POINTER(C.c_int)
     i32p, f32p, u8p = C.POINTER(C.c_int32), C.POINTER(C.c_float), C.POINTER(C.c_uint8)
     sig = {

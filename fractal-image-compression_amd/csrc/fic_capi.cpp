@@ -405,7 +405,7 @@ int q_sweep(fic_ctx* c, int tile0, int tile1, hipStream_t s, int* nchunks_out)
     tiles_per_chunk = (tiles_per_chunk + q.unroll - 1) / q.unroll * q.unroll;     // whole iterations of the unrolled sweep loop
     nchunks = (q.ndtiles + tiles_per_chunk - 1) / tiles_per_chunk;
     if (fic_launch_sweep_q(c->b, c->q_pool, c->q_flat, c->q_rng, c->q_rngC, c->q_E, c->q_thg, g, ct_begin, ct_end, q.ndtiles, q.ndtiles_alloc,
-                           q.nct_alloc, tiles_per_chunk, nchunks, s, c->q_stats))
+                           q.nct_alloc, tiles_per_chunk, nchunks, s, c->q_stats, c->opt_noflag))
         return fail(FIC_E_HIP, "k_sweep_q launch failed");
     *nchunks_out = nchunks;
     return FIC_OK;
@@ -726,6 +726,8 @@ int fic_ctx_set_option(fic_ctx* c, const char* name, int value)
     } else if (!strcmp(name, "chunks")) {
         if (value < 0) return fail(FIC_E_ARGUMENT, "chunks must be >= 0");
         c->opt_chunks = value;
+    } else if (!strcmp(name, "q_noflag")) {            // diagnostic: k_sweep_q without any flagged tile (wrong codebooks): its floor
+        c->opt_noflag = value ? 1 : 0;
     } else if (!strcmp(name, "time_sweep")) {
         c->opt_time = value ? 1 : 0;
     } else if (!strcmp(name, "sweep_stats")) {

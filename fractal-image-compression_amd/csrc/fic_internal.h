@@ -88,7 +88,7 @@ struct fic_ctx {
     bool encoded_any = false;
     hipStream_t last_stream = nullptr;
     hipStream_t own_stream = nullptr; // non-blocking stream of the multi-device entry (created on demand)
-    int opt_sweep = 0, opt_chunks = 0, opt_time = 0;
+    int opt_sweep = 0, opt_chunks = 0, opt_time = 0, opt_noflag = 0;
     int last_chunks = 0, last_kind = 0;
     std::vector<hipEvent_t> ev;      // pairs start/stop
     double acc_ms = 0.0;

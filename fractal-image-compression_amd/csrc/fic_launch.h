@@ -124,7 +124,7 @@ int fic_launch_q_prep(const FicBuffers& b, void* poolQ, void* dflat, void* rngQ,
                       const FicGeom& g, int ndtiles_alloc, int nct_alloc, int grp0, int ngrp, hipStream_t s);
 int fic_launch_sweep_q(const FicBuffers& b, const void* poolQ, const void* dflat, const void* rngQ, const void* rngC, const void* rngE,
                        void* theta_g, const FicGeom& g, int ct_begin, int ct_end, int ndtiles, int ndtiles_alloc,
-                       int nct_alloc, int tiles_per_chunk, int nchunks, hipStream_t s, unsigned long long* stats = nullptr);
+                       int nct_alloc, int tiles_per_chunk, int nchunks, hipStream_t s, unsigned long long* stats = nullptr, int dbg_noflag = 0);
 int fic_launch_decode_iteration_rgb(int32_t* scaled, int32_t* image, const int32_t* qrows5, FicDecodeState* state,
                                     uint32_t* sqbuf, int counter, const FicGeom& g, hipStream_t s);
 

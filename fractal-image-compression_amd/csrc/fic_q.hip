@@ -54,7 +54,8 @@ typedef float v16f __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 #define FIC_Q_LEVEL 0.99999237060546875f   // 1 - 2^-17
-#define FIC_Q_TAU_ALL 8192.0f              // > L of any pair (L <= ||r - rM|| <= 16 * 255)
+#define FIC_Q_TAU_ALL 3.0e38f              // "never flagged": above the test value of any pair (grey: L <= 16 * 255; joint RGB, where the
+                                           //   operand is greyD / vD with vD as small as 1: ~1e8)
 #define FIC_Q_TAU_NONE (-1.0f)             // nothing evaluated yet: every real pair of the tile is flagged
 #define FIC_Q_ECOEF 7.0e-4f                // >= 2^-10.5
 #define FIC_Q_EABS 1.6e-5f
@@ -382,6 +383,7 @@ struct QArgs {
     int ct_begin, ct_end;            // column tiles (x32 columns) of this shard
     int nctg;                        // column-tile groups (workgroups) in this launch
     int tiles_per_chunk, nchunks, planes;
+    int dbg_noflag;                  // diagnostic (option "q_noflag"): theta = "never" for every range -- the sweep's floor without any flagged tile (WRONG codebooks)
 };
 
 __device__ __forceinline__ v16f mfma_f16(v4i a, v4i b, v16f c)
@@ -573,7 +575,7 @@ __global__ __launch_bounds__(64 * FIC_Q_WPG, NK == 4 ? FIC_Q_WAVES_B8 : (NK < 4 
         const int rem = ok ? rst[j].rem : 0;
         E[ci] = ok ? A.rngE[(size_t)plane * A.Nr_pad + j] : 0.0f;
         // rem == 0: error 0 for every block (FC:677) -> only candidate 0 can win; padding: never flagged
-        tau[ci] = (ok && rem != 0) ? FIC_Q_TAU_NONE : FIC_Q_TAU_ALL;
+        tau[ci] = (ok && rem != 0 && !A.dbg_noflag) ? FIC_Q_TAU_NONE : FIC_Q_TAU_ALL;
         okbits |= ok ? 1u << ci : 0u;
         raise |= (ok && rem != 0) ? 1u << ci : 0u;
     }
@@ -806,10 +808,11 @@ int fic_launch_q_prep(const FicBuffers& b, void* poolQ, void* dflat, void* rngQ,
 
 int fic_launch_sweep_q(const FicBuffers& b, const void* poolQ, const void* dflat, const void* rngQ, const void* rngC, const void* rngE,
                        void* theta_g, const FicGeom& g, int ct_begin, int ct_end, int ndtiles, int ndtiles_alloc,
-                       int nct_alloc, int tiles_per_chunk, int nchunks, hipStream_t s, unsigned long long* stats)
+                       int nct_alloc, int tiles_per_chunk, int nchunks, hipStream_t s, unsigned long long* stats, int dbg_noflag)
 {
     QArgs A;
     A.stats = stats;
+    A.dbg_noflag = dbg_noflag;
     A.poolQ = (const v4i*)poolQ; A.dflat = (const uint32_t*)dflat; A.pool_pix = b.pool_pix; A.pool_st = b.pool_st;
     A.pool_s64 = b.pool_s64; A.rngQ = (const v4i*)rngQ; A.rngC = (const uint32_t*)rngC; A.rng_st = b.rng_st;
     A.rngE = (const float*)rngE; A.key = b.key; A.theta_g = (uint32_t*)theta_g;
@@ -956,6 +959,7 @@ int fic_launch_rgbq(const uint16_t* pool_sum, const FicRgbDomStat* pool_st, cons
     FIC_LAUNCH_CHECK();
     QArgs A;
     A.stats = nullptr;
+    A.dbg_noflag = 0;
     A.poolQ = (const v4i*)poolQ; A.dflat = (const uint32_t*)dflat; A.pool_pix = nullptr; A.pool_st = nullptr; A.pool_s64 = nullptr;
     A.rngQ = (const v4i*)rngQ; A.rngC = nullptr; A.rng_st = (const FicRngStat*)qst; A.rngE = (const float*)rngE; A.key = key;
     A.theta_g = (uint32_t*)theta_g;

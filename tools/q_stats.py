@@ -22,6 +22,8 @@ def run(W, B, n_iso, planes, dist="U", sweep=6, chunks=0, reps=5):
         enc.set_option("chunks", chunks)
     if sweep == 6:
         enc.set_option("sweep_stats", 1)
+    if os.environ.get("FIC_Q_NOFLAG"):
+        enc.set_option("q_noflag", 1)
     s = torch.cuda.current_stream()
     for _ in range(2):
         enc.encode(0, -1, s)
