@@ -108,6 +108,7 @@ def lib():
         "fic_debug_rccl_selftest": (C.c_int, [C.c_int]),
         "fic_debug_gather_fallbacks": (C.c_int, []),
         "fic_debug_float_sum": (C.c_int, [C.c_int, C.c_float, C.POINTER(C.c_uint32), C.c_int, f32p]),
+        "fic_debug_float_sum_fallbacks": (C.c_int, []),
         "fic_debug_decode_gray_run": (C.c_int, [u8p, C.c_int64, C.c_int, u8p, C.c_int64, f32p, ip, ip]),
         "fic_debug_sqrt_f64": (C.c_int, [C.c_int, C.c_uint32, C.c_uint32, C.POINTER(C.c_double)]),
         "fic_ctx_debug_pool_host": (C.c_int, [vp, u8p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), u8p]),
@@ -118,6 +119,12 @@ def lib():
         fn.argtypes = args
     _lib = L
     return L
+
+
+def has_xcheck():
+    """True when the library was built with round 1's exact-covariance matrix-core sweeps ("sweep" = 3 / 4; build.py,
+    FIC_BUILD_XCHECK, on by default) -- the test-suite's independent cross-checks of the default sweep."""
+    return b"+xcheck" in lib().fic_version()
 
 
 def last_error():

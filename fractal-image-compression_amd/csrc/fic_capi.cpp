@@ -229,6 +229,10 @@ int d4_sweep(fic_ctx* c, int tile0, int ntiles, hipStream_t s, int* nchunks_out)
     return FIC_OK;
 }
 
+// The exact-covariance matrix-core sweeps of round 1 ("sweep" = 3 / 4, fic_bf16.hip / fic_mfma.hip) lose to k_sweep_q everywhere; they are
+// kept as independent cross-checks for the test-suite (a third and fourth implementation of the same search) and are compiled
+// only into builds with FIC_BUILD_XCHECK (build.py: on by default, FIC_BUILD_XCHECK=0 for a deployment build).
+#ifdef FIC_BUILD_XCHECK
 // Opt-in matrix-core sweeps: geometry of the fragment stores.
 struct MatrixCoreShape {
     bool iso8;
@@ -336,6 +340,10 @@ int matrix_core_sweep(fic_ctx* c, int kind, int tile0, int tile1, hipStream_t s,
     return FIC_OK;
 }
 
+#else
+int matrix_core_prep(fic_ctx*, int, hipStream_t) { return fail(FIC_E_ARGUMENT, "sweep 3 / 4 (cross-check kernels) are not in this build (FIC_BUILD_XCHECK=0)"); }
+int matrix_core_sweep(fic_ctx*, int, int, int, hipStream_t, int*) { return fail(FIC_E_ARGUMENT, "sweep 3 / 4 (cross-check kernels) are not in this build (FIC_BUILD_XCHECK=0)"); }
+#endif
 // Default full-search sweep (fic_q.hip): shapes of its stores, fused prep (pool build + range prep + fragments), launch.
 struct QShape {
     int ndtiles, ndtiles_alloc;      // domain tiles (x32 blocks), + zero tiles for the unrolled loop's overrun and prefetch
@@ -415,7 +423,11 @@ int q_sweep(fic_ctx* c, int tile0, int tile1, hipStream_t s, int* nchunks_out)
 
 extern "C" {
 
-const char* fic_version(void) { return "fic-hip 0.1 (gfx950)"; }
+#ifdef FIC_BUILD_XCHECK
+const char* fic_version(void) { return "fic-hip 0.3 (gfx950, +xcheck sweeps)"; }
+#else
+const char* fic_version(void) { return "fic-hip 0.3 (gfx950)"; }
+#endif
 const char* fic_last_error(void) { return g_err.c_str(); }
 int fic_last_error_code(void) { return g_err_code; }
 
@@ -601,6 +613,9 @@ int fic_ctx_encode(fic_ctx* c, int range_begin, int range_count, void* hip_strea
         }
     }
     if (kind >= 2 && !g.full) return fail(FIC_E_ARGUMENT, "fast sweep needs full search (wK == Dw == Dh)");
+#ifndef FIC_BUILD_XCHECK
+    if (kind == 3 || kind == 4) return fail(FIC_E_ARGUMENT, "sweep %d (cross-check kernel) is not in this build (FIC_BUILD_XCHECK=0)", kind);
+#endif
     if (kind == 5 && !d4_available(g)) return fail(FIC_E_ARGUMENT, "sweep 5 (k_sweep_d4) needs full search, n_iso = 8 and B = 8");
     if (kind == 6 && g.Nd >= (1 << 24)) return fail(FIC_E_ARGUMENT, "sweep 6 (k_sweep_q) needs a pool of fewer than 2^24 blocks");
     const int tsz = 64 * g.NR;

@@ -58,6 +58,8 @@ void ficd::release_decoder_arenas()
     for (const Arena& a : drop) { (void)hipSetDevice(a.device); (void)hipFree(a.base); }
 }
 
+static thread_local int g_last_sum_fallbacks = 0;
+
 extern "C" {
 
 // Runs the reconstruction loop on the device.  Iterations are enqueued in groups of 8 and the
@@ -112,7 +114,7 @@ int fic_ctx_decode_host(fic_ctx* c, uint8_t* gray_out, float* avg_error_out, int
     size_t npix = (size_t)g.planes * g.W * g.H;
     if (!c->decoded) { int rc = dev_alloc(&c->decoded, npix); if (rc) return rc; }
     if (!c->dec_state) { int rc = dev_alloc(&c->dec_state, (size_t)g.planes); if (rc) return rc; }
-    if (!c->dec_sq) { int rc = dev_alloc(&c->dec_sq, npix); if (rc) return rc; }
+    if (!c->dec_sq) { int rc = dev_alloc(&c->dec_sq, fic_decode_sq_words((size_t)g.planes, (size_t)g.W * g.H)); if (rc) return rc; }
     HIP_TRY(hipStreamSynchronize(c->last_stream));
     int rc = run_decode_loop(g, c->b.scaled, c->decoded, c->o.qrows, g.n_iso > 1 ? c->o.iso : nullptr, c->dec_state, c->dec_sq,
                              nullptr, avg_error_out, iterations_out, nullptr, c->last_stream);
@@ -151,7 +153,7 @@ static int decode_gray_run_impl(const uint8_t* run, int64_t len, int device, uin
     const size_t npix = (size_t)w * h;
     const size_t o_scaled = 0, o_image = o_scaled + align256((size_t)g.Ws * g.Hs), o_q = o_image + align256(npix),
                  o_state = o_q + align256(q.size() * 4), o_sq = o_state + align256(sizeof(FicDecodeState)),
-                 total = o_sq + align256(npix * 4);
+                 total = o_sq + align256(fic_decode_sq_words(1, npix) * 4);
     Arena ar;
     rc = arena_take(device, total, &ar);
     if (rc) return rc;
@@ -185,19 +187,28 @@ int fic_debug_float_sum(int device, float carry, const uint32_t* vals, int count
     HIP_TRY(hipSetDevice(device));
     uint32_t* d = nullptr;
     float* r = nullptr;
+    uint32_t* maps = nullptr;
     HIP_TRY(hipMalloc((void**)&d, (size_t)(count + 4) * 4));
-    hipError_t e = hipMalloc((void**)&r, 4);
+    hipError_t e = hipMalloc((void**)&r, 8);
+    if (e == hipSuccess) e = hipMalloc((void**)&maps, (fic_float_sum_map_words((size_t)count) + 4) * 4);
     if (e == hipSuccess) e = hipMemcpy(d, vals, (size_t)count * 4, hipMemcpyHostToDevice);
     int rc = e == hipSuccess ? FIC_OK : fail(FIC_E_HIP, "fic_debug_float_sum: %s", hipGetErrorString(e));
-    if (rc == FIC_OK && fic_launch_float_sum_probe(carry, d, count, r, nullptr)) rc = fail(FIC_E_HIP, "k_float_sum_probe launch failed");
+    if (rc == FIC_OK && fic_launch_float_sum_probe(carry, d, count, maps, r, nullptr)) rc = fail(FIC_E_HIP, "k_float_sum_probe launch failed");
     if (rc == FIC_OK) {
-        e = hipMemcpy(out, r, 4, hipMemcpyDeviceToHost);
+        float two[2] = {0.0f, 0.0f};
+        e = hipMemcpy(two, r, 8, hipMemcpyDeviceToHost);
         if (e != hipSuccess) rc = fail(FIC_E_HIP, "fic_debug_float_sum: %s", hipGetErrorString(e));
+        out[0] = two[0];
+        g_last_sum_fallbacks = (int)two[1];
     }
     (void)hipFree(d);
     if (r) (void)hipFree(r);
+    if (maps) (void)hipFree(maps);
     return rc;
 }
+
+// Test hook: segments of the last fic_debug_float_sum on this thread that went through the sequential-order path.
+int fic_debug_float_sum_fallbacks(void) { return g_last_sum_fallbacks; }
 
 // Test hook: fic_decode_gray_run that also reports how many iterations needed the sequential (Java-order) float sum.
 int fic_debug_decode_gray_run(const uint8_t* run, int64_t len, int device, uint8_t* gray_out, int64_t capacity,
@@ -231,7 +242,7 @@ int fic_decode_rgb_run(const uint8_t* run, int64_t len, int device, int32_t* arg
     std::vector<int32_t> init(npix, (int32_t)0xff808080u);                          // generateGrayImage FC:1142-1148
     const size_t o_scaled = 0, o_image = o_scaled + align256((size_t)g.Ws * g.Hs * 4), o_q = o_image + align256(npix * 4),
                  o_state = o_q + align256(q.size() * 4), o_sq = o_state + align256(sizeof(FicDecodeState)),
-                 total = o_sq + align256(npix * 4);
+                 total = o_sq + align256(fic_decode_sq_words(1, npix) * 4);
     Arena ar;
     rc = arena_take(device, total, &ar);
     if (rc) return rc;

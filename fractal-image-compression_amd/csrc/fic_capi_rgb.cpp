@@ -293,7 +293,7 @@ int fic_rgb_ctx_decode_host(fic_rgb_ctx* c, int32_t* argb_out, float* avg_error_
     if (!c->dec_image) { int rc = dev_alloc(&c->dec_image, npix); if (rc) return rc; }
     if (!c->dec_scaled) { int rc = dev_alloc(&c->dec_scaled, (size_t)g.Ws * g.Hs); if (rc) return rc; }
     if (!c->dec_state) { int rc = dev_alloc(&c->dec_state, 1); if (rc) return rc; }
-    if (!c->dec_sq) { int rc = dev_alloc(&c->dec_sq, npix); if (rc) return rc; }
+    if (!c->dec_sq) { int rc = dev_alloc(&c->dec_sq, fic_decode_sq_words(1, npix)); if (rc) return rc; }
     hipStream_t s = c->last_stream;
     std::vector<int32_t> init(npix, (int32_t)0xff808080u);                          // generateGrayImage FC:1142-1148
     for (int p = 0; p < g.planes; p++) {

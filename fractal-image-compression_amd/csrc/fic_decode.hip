@@ -81,6 +81,37 @@ __global__ __launch_bounds__(256) void k_decode_paint(const uint8_t* __restrict_
 // restarts behind it; the head of the array is added in plain float while the carry-in still has a fractional part.
 #define FIC_SUM_THREADS 1024
 #define FIC_SUM_RUN 64
+#define FIC_SUM_SEG (FIC_SUM_THREADS * FIC_SUM_RUN)     // values one workgroup folds per round = one segment of the multi-workgroup scan
+#define FIC_SUM_SAT 16777216u                            // increments are kept up to 2^24: anything larger leaves the binade anyway
+#define FIC_SUM_KMAPS 20                                 // binades k = 0 .. 19 (ulp 2^k): from k = 20 on, half an ulp (2^19) exceeds every addend
+                                                         //   (a squared change is at most 3 * 255^2 = 195075), so the sum cannot move
+// (A0, A1) then (r0, r1): the map "first l, then r" -- increments for an even / odd input, saturating at FIC_SUM_SAT (a saturated
+// map stays saturated: its parity is meaningless, and so is everything composed behind it)
+__device__ __forceinline__ void map_compose(uint32_t& l0, uint32_t& l1, uint32_t r0, uint32_t r1)
+{
+    const uint32_t n0 = l0 + ((l0 & 1u) ? r1 : r0);                 // even input: parity after the left map = parity of l0
+    const uint32_t n1 = l1 + (((1u + l1) & 1u) ? r1 : r0);          // odd input
+    l0 = (l0 >= FIC_SUM_SAT || n0 >= FIC_SUM_SAT) ? FIC_SUM_SAT : n0;   // (all operands <= 2^24: no 32-bit wrap)
+    l1 = (l1 >= FIC_SUM_SAT || n1 >= FIC_SUM_SAT) ? FIC_SUM_SAT : n1;
+}
+// The map of FIC_SUM_RUN consecutive values (in registers) for binade k, as increments for an even / odd start.
+__device__ __forceinline__ void run_maps(const uint4 (&v4)[FIC_SUM_RUN / 4], int k, uint32_t& a0, uint32_t& a1)
+{
+    const uint32_t u_half = k > 0 ? 1u << (k - 1) : 0u, mask = k > 0 ? (1u << k) - 1u : 0u;
+    uint32_t m0 = 0, m1 = 1;                      // representatives with the right parity
+#pragma unroll
+    for (int j = 0; j < FIC_SUM_RUN; j++) {
+        const uint32_t v = (j & 3) == 0 ? v4[j >> 2].x : ((j & 3) == 1 ? v4[j >> 2].y : ((j & 3) == 2 ? v4[j >> 2].z : v4[j >> 2].w));
+        const uint32_t a = v >> k, r = v & mask;      // (zeros past the end change nothing: a = r = 0)
+        const uint32_t up = (k > 0 && r > u_half) ? 1u : 0u, tie = (k > 0 && r == u_half) ? 1u : 0u;
+        m0 = m0 + a;
+        m0 += up + (tie & m0 & 1u);
+        m1 = m1 + a;
+        m1 += up + (tie & m1 & 1u);
+    }
+    a0 = m0 < FIC_SUM_SAT ? m0 : FIC_SUM_SAT;     // (64 values below 2^18 each: no wrap before the clamp)
+    a1 = m1 - 1u < FIC_SUM_SAT ? m1 - 1u : FIC_SUM_SAT;
+}
 __device__ float java_float_sum(float carry, const uint32_t* __restrict__ d, int count)
 {
     __shared__ uint32_t f0[FIC_SUM_THREADS], f1[FIC_SUM_THREADS];      // maps, composed in place by the tree
@@ -107,32 +138,25 @@ __device__ float java_float_sum(float carry, const uint32_t* __restrict__ d, int
             int k = 0;
             if (sum >= 16777216.0f) k = (int)((__float_as_uint(sum) >> 23) & 0xFF) - 127 - 23;
             s_k = k;
-            s_m = (uint32_t)(sum * __uint_as_float((uint32_t)(127 - k) << 23));      // exact power-of-two scaling
+            s_m = k < FIC_SUM_KMAPS ? (uint32_t)(sum * __uint_as_float((uint32_t)(127 - k) << 23)) : 0u;   // exact power-of-two scaling
         }
         __syncthreads();
         const int k = s_k;
-        const uint32_t u_half = k > 0 ? 1u << (k - 1) : 0u, mask = k > 0 ? (1u << k) - 1u : 0u;
-        uint32_t a0 = 0, a1 = 1;                      // running m (mod 2^32) for an even / odd start, kept as increments + parity
+        if (k >= FIC_SUM_KMAPS) break;                // (uniform) half an ulp exceeds every addend: the sum no longer moves (FC:407)
+        uint32_t a0 = 0, a1 = 0;                      // increments for an even / odd start
         {
-            uint32_t m0 = 0, m1 = 1;                  // representatives with the right parity
             const int i0 = base + t * FIC_SUM_RUN;    // base is a multiple of 4 and d is 16-byte aligned: whole uint4 loads
             uint4 v4[FIC_SUM_RUN / 4];
 #pragma unroll
-            for (int j = 0; j < FIC_SUM_RUN / 4; j++)   // all loads in flight before the first use
-                v4[j] = (i0 + 4 * j < count) ? *(const uint4*)(d + i0 + 4 * j) : make_uint4(0, 0, 0, 0);
-#pragma unroll
-            for (int j = 0; j < FIC_SUM_RUN; j++) {
-                uint32_t v = (j & 3) == 0 ? v4[j >> 2].x : ((j & 3) == 1 ? v4[j >> 2].y : ((j & 3) == 2 ? v4[j >> 2].z : v4[j >> 2].w));
-                if (i0 + j >= count) v = 0;
-                const uint32_t a = v >> k, r = v & mask;      // (zeros past the end change nothing: a = r = 0)
-                const uint32_t up = (k > 0 && r > u_half) ? 1u : 0u, tie = (k > 0 && r == u_half) ? 1u : 0u;
-                m0 = m0 + a;
-                m0 += up + (tie & m0 & 1u);
-                m1 = m1 + a;
-                m1 += up + (tie & m1 & 1u);
+            for (int j = 0; j < FIC_SUM_RUN / 4; j++) {  // all loads in flight before the first use; values past the end read as 0
+                const int i = i0 + 4 * j;
+                uint4 v = (i < count) ? *(const uint4*)(d + i) : make_uint4(0, 0, 0, 0);
+                if (i + 1 >= count) v.y = 0;
+                if (i + 2 >= count) v.z = 0;
+                if (i + 3 >= count) v.w = 0;
+                v4[j] = v;
             }
-            a0 = m0;                                  // increment for an even input
-            a1 = m1 - 1u;                             // increment for an odd input
+            run_maps(v4, k, a0, a1);
         }
         f0[t] = a0;
         f1[t] = a1;
@@ -141,9 +165,10 @@ __device__ float java_float_sum(float carry, const uint32_t* __restrict__ d, int
         __syncthreads();
         for (int stride = 1; stride < FIC_SUM_THREADS; stride <<= 1) {
             if ((t & (2 * stride - 1)) == 0) {
-                const uint32_t l0 = f0[t], l1 = f1[t], r0 = f0[t + stride], r1 = f1[t + stride];
-                f0[t] = l0 + ((l0 & 1u) ? r1 : r0);                 // even input: parity after the left map = parity of l0
-                f1[t] = l1 + (((1u + l1) & 1u) ? r1 : r0);          // odd input
+                uint32_t l0 = f0[t], l1 = f1[t];
+                map_compose(l0, l1, f0[t + stride], f1[t + stride]);
+                f0[t] = l0;
+                f1[t] = l1;
             }
             __syncthreads();
         }
@@ -151,8 +176,9 @@ __device__ float java_float_sum(float carry, const uint32_t* __restrict__ d, int
             const uint32_t m = s_m;
             int end = base + FIC_SUM_THREADS * FIC_SUM_RUN;
             if (end > count) end = count;
-            const unsigned long long mn = (unsigned long long)m + ((m & 1u) ? f1[0] : f0[0]);
-            if (mn < 16777216ull && (unsigned long long)(uint32_t)((m & 1u) ? f1[0] : f0[0]) == (mn - m)) {
+            const uint32_t inc = (m & 1u) ? f1[0] : f0[0];            // saturated at 2^24: m + inc < 2^24 only for true increments
+            const unsigned long long mn = (unsigned long long)m + inc;
+            if (mn < 16777216ull) {
                 s_sum = (float)(uint32_t)mn * __uint_as_float((uint32_t)(127 + k) << 23);     // exact: m' < 2^24
             } else {
                 // The sum leaves the binade inside this block.  The per-thread maps are valid up to the thread in whose
@@ -178,20 +204,201 @@ __device__ float java_float_sum(float carry, const uint32_t* __restrict__ d, int
     return s_sum;
 }
 
-// Loop control of FC:413-417: one workgroup per plane.  avgError += ... (FC:407) is a float accumulation: fl(carry + SSD)
-// when that is provably what Java gets, else java_float_sum over sqbuf.
+// ---------------------------------------------------------------------------------------------
+// The same sum across the whole chip (round 3; round 2 walked the 16.8 M squares of a 4096x4096 iteration through ONE
+// workgroup, 256 rounds of 65 536: 4.4 ms for 67 MB).  The maps of java_float_sum compose associatively, so:
+//   k_float_sum_maps   every workgroup folds ONE segment of 65 536 values into its map (A0, A1) -- for EVERY binade k the sum can
+//                      be in while it crosses the segment (k = 0 .. kmax, kmax from the exact integer total): which binade that
+//                      will be is not known in advance, because the float sum may lag far behind the exact prefix (addends below
+//                      half an ulp leave it where it is);
+//   float_sum_walk     one workgroup walks the segments in order: binade and m of the running sum, the segment's map for that
+//                      binade, done -- unless the sum would leave the binade inside the segment (m + increment >= 2^24; the sum
+//                      only grows, so that happens at most ~20 times) or still has a fractional part: those segments, and only
+//                      those, go through java_float_sum.
+// maps: u32 [segments][FIC_SUM_KMAPS][2].
+// ---------------------------------------------------------------------------------------------
+__host__ __device__ inline int float_sum_segments(int count) { return (count + FIC_SUM_SEG - 1) / FIC_SUM_SEG; }
+// binade (ulp exponent) of a non-negative value: 0 below 2^24
+__device__ __forceinline__ int float_sum_binade(double v)
+{
+    int k = 0;
+    while (k < FIC_SUM_KMAPS - 1 && v >= 16777216.0 * (double)(1ull << k)) k++;
+    return k;
+}
+// exact integer total of one segment (u64), one workgroup of 256 threads per segment
+__device__ void float_sum_segment_total(const uint32_t* __restrict__ d, int count, int seg, unsigned long long* __restrict__ out)
+{
+    __shared__ unsigned long long part[4];
+    const int t = threadIdx.x;
+    unsigned long long acc = 0;
+    const int i0 = seg * FIC_SUM_SEG;
+    for (int i = i0 + 4 * t; i < i0 + FIC_SUM_SEG && i < count; i += 4 * 256) {
+        const uint4 v = *(const uint4*)(d + i);
+        acc += (unsigned long long)v.x + (i + 1 < count ? v.y : 0u);
+        acc += (unsigned long long)(i + 2 < count ? v.z : 0u) + (i + 3 < count ? v.w : 0u);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    if ((t & 63) == 0) part[t >> 6] = acc;
+    __syncthreads();
+    if (t == 0) out[seg] = part[0] + part[1] + part[2] + part[3];
+}
+// The maps of segment `seg` for the binades the running sum can be in while it crosses the segment; every other binade's
+// entry is "saturated" (the walk then takes the sequential-order path, which is always right).  Which binades: the float
+// sum F after i addends of exact total P_i obeys (carry + P_i) / f <= F <= f (carry + P_i) with f = (1 + 2^-24)^count --
+// every add rounds to nearest, relative error <= 2^-24 either way -- so with the exact totals of the segments before this
+// one (segtot) the sum enters the segment no lower than binade(lo / f) and leaves it no higher than binade(f hi).
+__device__ void float_sum_segment_maps(const uint32_t* __restrict__ d, int count, int seg, float carry, float f,
+                                       const unsigned long long* __restrict__ segtot, uint32_t* __restrict__ maps)
+{
+    __shared__ uint32_t w0[FIC_SUM_THREADS / 64], w1[FIC_SUM_THREADS / 64];
+    __shared__ unsigned long long pre[FIC_SUM_THREADS / 64];
+    __shared__ int s_klo, s_khi;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    {
+        unsigned long long acc = 0;                             // exact total of the segments before this one
+        for (int i = t; i < seg; i += FIC_SUM_THREADS) acc += segtot[i];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
+        if (lane == 0) pre[wave] = acc;
+        __syncthreads();
+        if (t == 0) {
+            unsigned long long before = 0;
+            for (int w = 0; w < FIC_SUM_THREADS / 64; w++) before += pre[w];
+            const double c = carry > 0.0f ? (double)carry : 0.0, ff = (double)f;
+            int klo = float_sum_binade(((double)before + c) / ff - 1.0);
+            int khi = float_sum_binade(((double)(before + segtot[seg]) + c) * ff + 1.0);
+            if (!(carry == carry) || carry < 0.0f) { klo = 1; khi = 0; }      // NaN / negative carry-in: no map, sequential-order path
+            s_klo = klo;
+            s_khi = khi;
+        }
+        __syncthreads();
+    }
+    const int klo = s_klo, khi = s_khi;
+    for (int k = t; k < FIC_SUM_KMAPS; k += FIC_SUM_THREADS)
+        if (k < klo || k > khi) {
+            maps[((size_t)seg * FIC_SUM_KMAPS + k) * 2 + 0] = FIC_SUM_SAT;
+            maps[((size_t)seg * FIC_SUM_KMAPS + k) * 2 + 1] = FIC_SUM_SAT;
+        }
+    if (klo > khi) return;
+    const int i0 = seg * FIC_SUM_SEG + t * FIC_SUM_RUN;
+    uint4 v4[FIC_SUM_RUN / 4];
+#pragma unroll
+    for (int j = 0; j < FIC_SUM_RUN / 4; j++) {
+        const int i = i0 + 4 * j;
+        uint4 v = (i < count) ? *(const uint4*)(d + i) : make_uint4(0, 0, 0, 0);
+        if (i + 1 >= count) v.y = 0;
+        if (i + 2 >= count) v.z = 0;
+        if (i + 3 >= count) v.w = 0;
+        v4[j] = v;
+    }
+    for (int k = klo; k <= khi; k++) {
+        uint32_t a0, a1;
+        run_maps(v4, k, a0, a1);
+        // ordered composition: lanes of a wave by shuffles (lane t absorbs lane t + stride), then the 16 waves
+#pragma unroll
+        for (int stride = 1; stride < 64; stride <<= 1) {
+            const uint32_t r0 = __shfl_down(a0, stride, 64), r1 = __shfl_down(a1, stride, 64);
+            if ((lane & (2 * stride - 1)) == 0) map_compose(a0, a1, r0, r1);
+        }
+        if (lane == 0) { w0[wave] = a0; w1[wave] = a1; }
+        __syncthreads();
+        if (t == 0) {
+            uint32_t l0 = w0[0], l1 = w1[0];
+            for (int w = 1; w < FIC_SUM_THREADS / 64; w++) map_compose(l0, l1, w0[w], w1[w]);
+            maps[((size_t)seg * FIC_SUM_KMAPS + k) * 2 + 0] = l0;
+            maps[((size_t)seg * FIC_SUM_KMAPS + k) * 2 + 1] = l1;
+        }
+        __syncthreads();
+    }
+}
+// the walk over the segments; every thread of the workgroup returns the sum
+__device__ float float_sum_walk(float carry, const uint32_t* __restrict__ d, int count, const uint32_t* __restrict__ maps, int* fallbacks)
+{
+    __shared__ float w_sum;
+    __shared__ int w_seg;
+    const int t = threadIdx.x, nseg = float_sum_segments(count);
+    if (t == 0) { w_sum = carry; w_seg = 0; }
+    __syncthreads();
+    for (;;) {
+        if (t == 0) {
+            float sum = w_sum;
+            int seg = w_seg;
+            while (seg < nseg) {
+                if (!(sum == sum) || sum >= 16777216.0f * (float)(1u << (FIC_SUM_KMAPS - 1))) { seg = nseg; break; }   // NaN, or too large to move
+                if (sum != truncf(sum) || sum < 0.0f) break;                                  // fractional carry-in: java_float_sum's head
+                int k = 0;
+                if (sum >= 16777216.0f) k = (int)((__float_as_uint(sum) >> 23) & 0xFF) - 127 - 23;
+                if (k >= FIC_SUM_KMAPS) break;
+                const uint32_t m = (uint32_t)(sum * __uint_as_float((uint32_t)(127 - k) << 23));
+                const uint32_t inc = maps[((size_t)seg * FIC_SUM_KMAPS + k) * 2 + (m & 1u)];
+                if (inc >= FIC_SUM_SAT || m + inc >= FIC_SUM_SAT) break;                      // leaves the binade inside this segment
+                sum = (float)(m + inc) * __uint_as_float((uint32_t)(127 + k) << 23);          // exact: m' < 2^24
+                seg++;
+            }
+            w_sum = sum;
+            w_seg = seg;
+        }
+        __syncthreads();
+        const int seg = w_seg;
+        if (seg >= nseg) break;
+        const int len = count - seg * FIC_SUM_SEG < FIC_SUM_SEG ? count - seg * FIC_SUM_SEG : FIC_SUM_SEG;
+        const float s2 = java_float_sum(w_sum, d + (size_t)seg * FIC_SUM_SEG, len);
+        __syncthreads();
+        if (t == 0) {
+            w_sum = s2;
+            w_seg = seg + 1;
+            if (fallbacks) *fallbacks += 1;
+        }
+        __syncthreads();
+    }
+    return w_sum;
+}
+
+// Loop control of FC:413-417.  avgError += ... (FC:407) is a float accumulation: fl(carry + SSD) when that is provably what
+// Java gets (every partial sum an exact float), else the scan above over sqbuf: k_decode_maps on every CU, then k_decode_step.
+__device__ __forceinline__ bool decode_sum_is_exact(float carry, unsigned long long ssd)
+{
+    return carry == truncf(carry) && carry >= 0.0f && (double)carry + (double)ssd < 16777216.0;
+}
+// scratch of one plane behind the squares: maps u32 [segments][KMAPS][2], then the segments' exact totals u64 [segments]
+__host__ __device__ inline size_t float_sum_scratch_words(int count) { return (size_t)float_sum_segments(count) * (FIC_SUM_KMAPS * 2 + 2); }
+__device__ __forceinline__ unsigned long long* float_sum_totals(uint32_t* scratch, int count)
+{
+    return (unsigned long long*)(scratch + (size_t)float_sum_segments(count) * FIC_SUM_KMAPS * 2);
+}
+__global__ __launch_bounds__(256) void k_decode_segtot(const FicDecodeState* __restrict__ state, const uint32_t* __restrict__ sqbuf,
+                                                       uint32_t* __restrict__ scratch, int counter, int wh)
+{
+    const int plane = blockIdx.y;
+    const FicDecodeState* st = state + plane;
+    if (st->done || decode_sum_is_exact(st->avg, st->ssd[counter])) return;      // uniform per workgroup
+    float_sum_segment_total(sqbuf + (size_t)plane * wh, wh, blockIdx.x, float_sum_totals(scratch + plane * float_sum_scratch_words(wh), wh));
+}
+__global__ __launch_bounds__(FIC_SUM_THREADS) void k_decode_maps(const FicDecodeState* __restrict__ state, const uint32_t* __restrict__ sqbuf,
+                                                                uint32_t* __restrict__ scratch, int counter, int wh, float f)
+{
+    const int plane = blockIdx.y, seg = blockIdx.x;
+    const FicDecodeState* st = state + plane;
+    if (st->done) return;                                      // uniform per workgroup
+    const float carry = st->avg;
+    if (decode_sum_is_exact(carry, st->ssd[counter])) return;
+    uint32_t* sc = scratch + plane * float_sum_scratch_words(wh);
+    float_sum_segment_maps(sqbuf + (size_t)plane * wh, wh, seg, carry, f, float_sum_totals(sc, wh), sc);
+}
 __global__ __launch_bounds__(FIC_SUM_THREADS) void k_decode_step(FicDecodeState* __restrict__ state,
-                                                                const uint32_t* __restrict__ sqbuf, int counter, int wh, int planes)
+                                                                const uint32_t* __restrict__ sqbuf, const uint32_t* __restrict__ maps,
+                                                                int counter, int wh, int planes)
 {
     const int plane = blockIdx.x;
     FicDecodeState* st = state + plane;
     if (st->done) return;                                      // uniform per workgroup
     const float carry = st->avg;                               // 0 after iteration 0; the static's old value before it (FC:20)
     const unsigned long long ssd = st->ssd[counter];
-    const bool exact = carry == truncf(carry) && carry >= 0.0f && (double)carry + (double)ssd < 16777216.0;
+    const bool exact = decode_sum_is_exact(carry, ssd);
     float avg;
     if (exact) avg = __fadd_rn(carry, (float)ssd);             // every partial sum is an exact float: order is irrelevant
-    else avg = java_float_sum(carry, sqbuf + (size_t)plane * wh, wh);
+    else avg = float_sum_walk(carry, sqbuf + (size_t)plane * wh, wh, maps + plane * float_sum_scratch_words(wh), nullptr);
     if (threadIdx.x != 0) return;
     if (!exact) st->seq_sums += 1;
     avg = __fdiv_rn(avg, (float)wh);                           // FC:413
@@ -202,25 +409,59 @@ __global__ __launch_bounds__(FIC_SUM_THREADS) void k_decode_step(FicDecodeState*
     if (counter == 49) st->done = 1;
 }
 
-// test hook: out[0] = java_float_sum(carry, vals, count)
-__global__ __launch_bounds__(FIC_SUM_THREADS) void k_float_sum_probe(float carry, const uint32_t* __restrict__ vals, int count,
-                                                                    float* __restrict__ out)
+// test hook: out[0] = Java's sum through the same code as the decoder (segment totals, segment maps on every CU, then the
+// walk); out[1] = segments that went through java_float_sum
+__global__ __launch_bounds__(256) void k_float_sum_probe_tot(const uint32_t* __restrict__ vals, int count, uint32_t* __restrict__ scratch)
 {
-    const float r = java_float_sum(carry, vals, count);
-    if (threadIdx.x == 0) out[0] = r;
+    float_sum_segment_total(vals, count, blockIdx.x, float_sum_totals(scratch, count));
 }
-int fic_launch_float_sum_probe(float carry, const uint32_t* vals, int count, float* out, hipStream_t s)
+__global__ __launch_bounds__(FIC_SUM_THREADS) void k_float_sum_probe_maps(float carry, const uint32_t* __restrict__ vals, int count,
+                                                                         uint32_t* __restrict__ scratch, float f)
 {
-    hipLaunchKernelGGL(k_float_sum_probe, dim3(1), dim3(FIC_SUM_THREADS), 0, s, carry, vals, count, out);
+    float_sum_segment_maps(vals, count, blockIdx.x, carry, f, float_sum_totals(scratch, count), scratch);
+}
+__global__ __launch_bounds__(FIC_SUM_THREADS) void k_float_sum_probe(float carry, const uint32_t* __restrict__ vals, int count,
+                                                                    const uint32_t* __restrict__ scratch, float* __restrict__ out)
+{
+    __shared__ int fb;
+    if (threadIdx.x == 0) fb = 0;
+    __syncthreads();
+    const float r = float_sum_walk(carry, vals, count, scratch, &fb);
+    if (threadIdx.x == 0) { out[0] = r; out[1] = (float)fb; }
+}
+// (1 + 2^-24)^count, rounded up: how far the float sum of `count` addends can drift from the exact total, as a factor
+static float float_sum_drift(size_t count) { return (float)(exp((double)count * 5.9604645e-8 * 1.0001) * 1.0001); }
+size_t fic_float_sum_map_words(size_t count) { return float_sum_scratch_words((int)count); }
+// u32 words of the decoder's scratch for `planes` images of wh pixels: the squares in Java's visiting order + the scan's scratch
+size_t fic_decode_sq_words(size_t planes, size_t wh) { return planes * (wh + float_sum_scratch_words((int)wh)); }
+int fic_launch_float_sum_probe(float carry, const uint32_t* vals, int count, uint32_t* scratch, float* out2, hipStream_t s)
+{
+    if (count > 0) {
+        const int nseg = float_sum_segments(count);
+        hipLaunchKernelGGL(k_float_sum_probe_tot, dim3(nseg), dim3(256), 0, s, vals, count, scratch);
+        FIC_LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_float_sum_probe_maps, dim3(nseg), dim3(FIC_SUM_THREADS), 0, s, carry, vals, count, scratch, float_sum_drift((size_t)count));
+        FIC_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(k_float_sum_probe, dim3(1), dim3(FIC_SUM_THREADS), 0, s, carry, vals, count, (const uint32_t*)scratch, out2);
     FIC_LAUNCH_CHECK();
     return 0;
 }
 
 // host-side launchers
-// loop control of one decoder iteration (shared by the grey and the RGB decoder)
-int fic_launch_decode_step(FicDecodeState* state, const uint32_t* sqbuf, int counter, int wh, int planes, hipStream_t s)
+// loop control of one decoder iteration (shared by the grey and the RGB decoder); sqbuf: fic_decode_sq_words(planes, wh) words
+int fic_launch_decode_step(FicDecodeState* state, uint32_t* sqbuf, int counter, int wh, int planes, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_decode_step, dim3(planes), dim3(FIC_SUM_THREADS), 0, s, state, sqbuf, counter, wh, planes);
+    uint32_t* scratch = sqbuf + (size_t)planes * wh;
+    const int nseg = float_sum_segments(wh);
+    hipLaunchKernelGGL(k_decode_segtot, dim3(nseg, planes), dim3(256), 0, s, (const FicDecodeState*)state, (const uint32_t*)sqbuf, scratch,
+                       counter, wh);
+    FIC_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_decode_maps, dim3(nseg, planes), dim3(FIC_SUM_THREADS), 0, s, (const FicDecodeState*)state,
+                       (const uint32_t*)sqbuf, scratch, counter, wh, float_sum_drift((size_t)wh));
+    FIC_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_decode_step, dim3(planes), dim3(FIC_SUM_THREADS), 0, s, state, (const uint32_t*)sqbuf, (const uint32_t*)scratch,
+                       counter, wh, planes);
     FIC_LAUNCH_CHECK();
     return 0;
 }

@@ -129,8 +129,12 @@ int fic_launch_decode_iteration_rgb(int32_t* scaled, int32_t* image, const int32
                                     uint32_t* sqbuf, int counter, const FicGeom& g, hipStream_t s);
 
 // decoder (FC:356-421)
-int fic_launch_float_sum_probe(float carry, const uint32_t* vals, int count, float* out, hipStream_t s);
+// maps: fic_float_sum_map_words(count) u32 of scratch; out2[0] = the sum, out2[1] = segments that took the sequential-order path
+int fic_launch_float_sum_probe(float carry, const uint32_t* vals, int count, uint32_t* maps, float* out2, hipStream_t s);
+size_t fic_float_sum_map_words(size_t count);
+// u32 words of the decoder's `sqbuf` scratch for `planes` images of wh pixels (squares + segment maps of the float sum)
+size_t fic_decode_sq_words(size_t planes, size_t wh);
 // sqbuf: u32 [planes][W*H] per-pixel squared changes of the iteration in Java's visiting order (for the sequential f32 sum)
-int fic_launch_decode_step(FicDecodeState* state, const uint32_t* sqbuf, int counter, int wh, int planes, hipStream_t s);
+int fic_launch_decode_step(FicDecodeState* state, uint32_t* sqbuf, int counter, int wh, int planes, hipStream_t s);
 int fic_launch_decode_iteration(uint8_t* scaled, uint8_t* image, const int32_t* qrows, const int32_t* iso,
                                 FicDecodeState* state, uint32_t* sqbuf, int counter, const FicGeom& g, hipStream_t s);

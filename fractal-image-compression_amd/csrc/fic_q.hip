@@ -95,6 +95,7 @@ __device__ __forceinline__ int f16_pair(float lo, float hi)
 //   poolQ[plane][dtile][m][lane] = 8 f16 = normalised pixels [16m + 8h, +8) of block 32*dtile + (lane&31), h = lane>>5.
 //   dflat[plane][dtile] = 1 (u32) when all 32 blocks are flat or beyond N_d (their fragments are zero).
 // ---------------------------------------------------------------------------------------------
+template <int B>
 __global__ __launch_bounds__(256) void k_pool_q(const uint8_t* __restrict__ scaled, uint8_t* __restrict__ pool_pix,
                                                 FicDomStat* __restrict__ pool_st, uint32_t* __restrict__ pool_var,
                                                 double* __restrict__ pool_s64, v4i* __restrict__ poolQ,
@@ -105,35 +106,39 @@ __global__ __launch_bounds__(256) void k_pool_q(const uint8_t* __restrict__ scal
     __shared__ float s_w[32];
     __shared__ int s_mean[32];
     __shared__ int s_nonflat;
-    const int B = g.B, n = g.n, NK = n / 16;
+    constexpr int n = B * B, NK = n / 16;
     const int dtile = blockIdx.x, plane = blockIdx.y;
     if (threadIdx.x == 0) s_nonflat = 0;
-    // (a) rows of the tile's blocks: thread = (block i, row ry)
+    // (a) rows of the tile's blocks: thread = (block i, row ry); a row is ONE load of B bytes (the address is only abstand-aligned:
+    //     gfx950 global loads take that), byte sums by v_sad_u8, squares by v_dot4
     for (int t = threadIdx.x; t < 32 * B; t += 256) {
         const int i = t / B, ry = t % B;
         const int d = dtile * 32 + i;
-        int sum = 0, sq = 0;
-        uint8_t* dst = &pix[i][ry * B];
+        uint32_t w[B / 4];
+#pragma unroll
+        for (int q = 0; q < B / 4; q++) w[q] = 0u;
         if (d < g.Nd) {
             const int c = d % g.Dw, r = d / g.Dw;
             const uint8_t* src = scaled + (size_t)plane * g.Ws * g.Hs + (size_t)(r * g.abstand + ry) * g.Ws + c * g.abstand;
-            for (int rx = 0; rx < B; rx++) {
-                const int v = src[rx];
-                dst[rx] = (uint8_t)v;
-                sum += v;
-                sq += v * v;
-            }
-            uint8_t* out = pool_pix + ((size_t)plane * g.Nd_pad + d) * n + ry * B;
-            if (B == 4) *(uint32_t*)out = *(const uint32_t*)dst;
-            else if (B == 8) *(uint2*)out = *(const uint2*)dst;
-            else *(uint4*)out = *(const uint4*)dst;
-        } else {
-            for (int rx = 0; rx < B; rx++) dst[rx] = 0;
+            __builtin_memcpy(w, src, B);
         }
-        s_sum[i][ry] = sum;
-        s_sq[i][ry] = sq;
+        uint32_t sum = 0, sq = 0;
+#pragma unroll
+        for (int q = 0; q < B / 4; q++) {
+            sum = __builtin_amdgcn_sad_u8(w[q], 0u, sum);
+            sq = __builtin_amdgcn_udot4(w[q], w[q], sq, false);
+            *(uint32_t*)&pix[i][ry * B + 4 * q] = w[q];
+        }
+        s_sum[i][ry] = (int)sum;
+        s_sq[i][ry] = (int)sq;
     }
     __syncthreads();
+    // the tile's 32 blocks are 32 n contiguous bytes of pool_pix: 16 bytes per lane, straight from LDS
+    for (int t = threadIdx.x; t < 32 * n / 16; t += 256) {
+        const int i = t / (n / 16), q = t % (n / 16);
+        const int d = dtile * 32 + i;
+        if (d < g.Nd) *(uint4*)(pool_pix + ((size_t)plane * g.Nd_pad + d) * n + 16 * q) = *(const uint4*)&pix[i][16 * q];
+    }
     // (b) per-block statistics
     if (threadIdx.x < 32) {
         const int i = threadIdx.x, d = dtile * 32 + i;
@@ -282,10 +287,14 @@ __global__ __launch_bounds__(256) void k_range_q(const uint8_t* __restrict__ gra
         const int s0 = cx + cy * B, sx = ax + ay * B, sy = bx + by * B;                 // source index = s0 + sx*x + sy*y
         const uint8_t* b = blk + l * stride;
         uint32_t w = 0;
+        if (k == 0) {
+            w = *(const uint32_t*)(b + 4 * wd);                // the identity copy: the block's own dword (stride is a multiple of 4)
+        } else {
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int p = 4 * wd + u;
-            w |= (uint32_t)b[s0 + sx * (p & (B - 1)) + sy * (p >> lgB)] << (8 * u);
+            for (int u = 0; u < 4; u++) {
+                const int p = 4 * wd + u;
+                w |= (uint32_t)b[s0 + sx * (p & (B - 1)) + sy * (p >> lgB)] << (8 * u);
+            }
         }
         rngC[((size_t)plane * g.Nr_pad * cpr + (size_t)j0 * cpr + col) * DW + wd] = w;
         if (staged) *(uint32_t*)(cpy + col * cstride + 4 * wd) = w;
@@ -338,6 +347,163 @@ __global__ __launch_bounds__(256) void k_range_q(const uint8_t* __restrict__ gra
                     const int c0 = b[s0 + sx * (p & (B - 1)) + sy * (p >> lgB)], c1 = b[s0 + sx * (pr & (B - 1)) + sy * (pr >> lgB)];
                     a[u] = odd ? c0 - c1 : c0 + c1 - 2 * rM;
                 }
+            }
+        }
+        v4i v;
+#pragma unroll
+        for (int u = 0; u < 4; u++) v[u] = real ? f16_pair((float)a[2 * u], (float)a[2 * u + 1]) : 0;
+        if (ct0 + ctl < nct_alloc) rngQ[((size_t)plane * nct_alloc + ct0 + ctl) * NK * 64 + (size_t)m * 64 + lane] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_range_q8<MODE> : k_range_q for B = 8 (MODE 0: 1 isometry, MODE 2: 8 isometries folded) -- the two shapes the benchmark
+// spends its range prep on.  Same outputs, bit for bit; what differs is how the bytes move:
+//   * range rows enter LDS as 8-byte loads; statistics as in k_range_q;
+//   * the four copies of a block (the first isometries of the folded pairs: identity, rot 90, mirror, transpose -- gathered
+//     through the INVERSE map) are made in registers, one wave per copy: a block is 16 dwords, a mirror is
+//     a byte swap per dword, an 8x8 byte transpose is 32 v_perm_b32 (four 4x4 tiles, two stages each) -- instead of four
+//     ds_read_u8 + shifts per output dword;
+//   * rngC leaves as 16 bytes per lane, contiguous over the workgroup (it is 64 B per column, columns consecutive).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void t4x4_bytes(uint32_t a, uint32_t b, uint32_t c, uint32_t d, uint32_t& o0, uint32_t& o1, uint32_t& o2, uint32_t& o3)
+{
+    // rows a, b, c, d of a 4x4 byte tile -> its columns (v_perm_b32: selector bytes 0-3 pick from the second source, 4-7 from the first)
+    const uint32_t t0 = __builtin_amdgcn_perm(b, a, 0x06020400u), t1 = __builtin_amdgcn_perm(b, a, 0x07030501u);
+    const uint32_t t2 = __builtin_amdgcn_perm(d, c, 0x06020400u), t3 = __builtin_amdgcn_perm(d, c, 0x07030501u);
+    o0 = __builtin_amdgcn_perm(t2, t0, 0x05040100u);
+    o1 = __builtin_amdgcn_perm(t3, t1, 0x05040100u);
+    o2 = __builtin_amdgcn_perm(t2, t0, 0x07060302u);
+    o3 = __builtin_amdgcn_perm(t3, t1, 0x07060302u);
+}
+// out[y][x] = in[x][y] of an 8x8 byte block held as 16 dwords (row y = dwords 2y, 2y + 1)
+__device__ __forceinline__ void b8_transpose(const uint32_t (&r)[16], uint32_t (&o)[16])
+{
+#pragma unroll
+    for (int ty = 0; ty < 2; ty++)
+#pragma unroll
+        for (int tx = 0; tx < 2; tx++)
+            t4x4_bytes(r[2 * (4 * ty + 0) + tx], r[2 * (4 * ty + 1) + tx], r[2 * (4 * ty + 2) + tx], r[2 * (4 * ty + 3) + tx],
+                       o[2 * (4 * tx + 0) + ty], o[2 * (4 * tx + 1) + ty], o[2 * (4 * tx + 2) + ty], o[2 * (4 * tx + 3) + ty]);
+}
+// out[y][x] = in[y][7 - x]
+__device__ __forceinline__ void b8_mirror(const uint32_t (&r)[16], uint32_t (&o)[16])
+{
+#pragma unroll
+    for (int y = 0; y < 8; y++) {
+        o[2 * y] = __builtin_bswap32(r[2 * y + 1]);
+        o[2 * y + 1] = __builtin_bswap32(r[2 * y]);
+    }
+}
+template <int MODE>
+__global__ __launch_bounds__(256) void k_range_q8(const uint8_t* __restrict__ gray, FicRngStat* __restrict__ rng_st,
+                                                  float* __restrict__ rngE, unsigned long long* __restrict__ key,
+                                                  uint32_t* __restrict__ theta_g, v4i* __restrict__ rngQ,
+                                                  uint32_t* __restrict__ rngC, FicGeom g, int nct_alloc, int grp0)
+{
+    constexpr int B = 8, n = 64, DW = 16, NK = 4, CPR = MODE == 0 ? 1 : 4, STR = 80;     // STR: LDS bytes per block / copy (16-byte aligned rows)
+    __shared__ __attribute__((aligned(16))) uint8_t blk[64 * STR];
+    __shared__ __attribute__((aligned(16))) uint8_t cpy[MODE == 0 ? 16 : 256 * STR];
+    __shared__ int s_rM[64];
+    const int plane = blockIdx.y;
+    const int j0 = (grp0 + blockIdx.x) * 64;
+    const uint8_t* img = gray + (size_t)plane * g.W * g.H;
+    for (int i = threadIdx.x; i < 64 * B; i += 256) {          // one 8-byte row per thread and pass
+        const int l = i >> 3, ry = i & 7;
+        const int j = j0 + l;
+        uint2 v = make_uint2(0u, 0u);
+        if (j < g.Nr) v = *(const uint2*)(img + (size_t)((j / g.Rw) * B + ry) * g.W + (j % g.Rw) * B);   // W, B multiples of 8: aligned
+        *(uint2*)&blk[l * STR + ry * B] = v;
+    }
+    __syncthreads();
+    {
+        const int l = threadIdx.x >> 2, part = threadIdx.x & 3;   // 4 threads per block, 4 words each
+        const uint4 w4 = *(const uint4*)(blk + l * STR + part * 16);
+        const uint32_t w[4] = {w4.x, w4.y, w4.z, w4.w};
+        uint32_t S = 0, Q = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            S = __builtin_amdgcn_sad_u8(w[i], 0u, S);
+            Q = __builtin_amdgcn_udot4(w[i], w[i], Q, false);
+        }
+        S += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)S, 0xB1, 0xF, 0xF, true);   // quad: lanes 1,0,3,2
+        Q += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)Q, 0xB1, 0xF, 0xF, true);
+        S += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)S, 0x4E, 0xF, 0xF, true);   // quad: lanes 2,3,0,1
+        Q += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)Q, 0x4E, 0xF, 0xF, true);
+        const int j = j0 + l;
+        const int rM = (int)(S >> 6);
+        if (part == 0) {
+            s_rM[l] = rM;
+            if (j < g.Nr_pad) {
+                const int ss = (int)Q - 2 * rM * (int)S + n * rM * rM;                    // sum (r - rM)^2, exact integer
+                const size_t o = (size_t)plane * g.Nr_pad + j;
+                FicRngStat st;
+                st.rM = j < g.Nr ? rM : 0;
+                st.rem = j < g.Nr ? (int)S - (rM << 6) : 0;
+                rng_st[o] = st;
+                rngE[o] = __fadd_rn(__fmul_rn(__fsqrt_rn((float)ss), FIC_Q_ECOEF), FIC_Q_EABS);
+                key[o] = FIC_KEY_NONE;
+                theta_g[o] = 0u;
+            }
+        }
+    }
+    if constexpr (MODE == 2) {
+        // wave c makes copy c of all 64 blocks: c = 0 identity, 1 = isometry 1 (gathered through its inverse, rot 270:
+        // transpose of the mirror), 2 = isometry 4 (mirror left-right), 3 = isometry 6 (transpose)
+        const int c = threadIdx.x >> 6, l = threadIdx.x & 63;
+        uint32_t r[16], o[16];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const uint4 v = *(const uint4*)(blk + l * STR + 16 * q);
+            r[4 * q] = v.x; r[4 * q + 1] = v.y; r[4 * q + 2] = v.z; r[4 * q + 3] = v.w;
+        }
+        if (c == 0) {
+#pragma unroll
+            for (int q = 0; q < 16; q++) o[q] = r[q];
+        } else if (c == 1) {
+            uint32_t m[16];
+            b8_mirror(r, m);
+            b8_transpose(m, o);
+        } else if (c == 2) {
+            b8_mirror(r, o);
+        } else {
+            b8_transpose(r, o);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) *(uint4*)(cpy + (l * 4 + c) * STR + 16 * q) = make_uint4(o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]);
+    }
+    __syncthreads();
+    const uint8_t* const cps = MODE == 0 ? blk : cpy;           // the columns' copies as bytes, STR apart
+    constexpr int cols = 64 * CPR;
+    const int ct0 = (j0 * CPR) / 32;
+    // rngC: cols x 64 bytes, contiguous: 16 bytes per lane
+    for (int t = threadIdx.x; t < cols * 4; t += 256) {
+        const int col = t >> 2, q = t & 3;
+        if (j0 + col / CPR < g.Nr_pad)
+            *(uint4*)(rngC + ((size_t)plane * g.Nr_pad * CPR + (size_t)j0 * CPR + col) * DW + 4 * q) = *(const uint4*)(cps + col * STR + 16 * q);
+    }
+    // fragments: thread = (column tile, m, lane), exactly as the staged branch of k_range_q
+    for (int t = threadIdx.x; t < (cols / 32) * NK * 64; t += 256) {
+        const int lane = t & 63, m = (t >> 6) % NK, ctl = (t >> 6) / NK;
+        const int col = ctl * 32 + (lane & 31), h = lane >> 5;
+        const int l = col / CPR;
+        const int rM = s_rM[l];
+        const bool real = j0 + l < g.Nr;
+        const uint8_t* cp = cps + col * STR;
+        int a[8];
+        if constexpr (MODE != 2) {
+            const uint2 w = *(const uint2*)(cp + 16 * m + 8 * h);
+#pragma unroll
+            for (int u = 0; u < 8; u++) a[u] = (int)(((u < 4 ? w.x : w.y) >> (8 * (u & 3))) & 0xffu) - rM;
+        } else {
+            const bool odd = m >= NK / 2;
+            const int q0 = 16 * (odd ? m - NK / 2 : m) + 8 * h;
+            const uint2 w = *(const uint2*)(cp + q0), v = *(const uint2*)(cp + n - 8 - q0);   // v: positions n-8-q0 .. n-1-q0
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int c0 = (int)(((u < 4 ? w.x : w.y) >> (8 * (u & 3))) & 0xffu);
+                const int c1 = (int)(((u < 4 ? v.y : v.x) >> (8 * (3 - (u & 3)))) & 0xffu);    // position n-1-(q0+u)
+                a[u] = odd ? c0 - c1 : c0 + c1 - 2 * rM;
             }
         }
         v4i v;
@@ -794,14 +960,21 @@ int fic_launch_q_prep(const FicBuffers& b, void* poolQ, void* dflat, void* rngQ,
                       const FicGeom& g, int ndtiles_alloc, int nct_alloc, int grp0, int ngrp, hipStream_t s)
 {
     const int mode = fic_q_mode(g.B, g.n_iso);
-    hipLaunchKernelGGL(k_pool_q, dim3(ndtiles_alloc, g.planes), dim3(256), 0, s, (const uint8_t*)b.scaled, b.pool_pix,
+    auto pool = g.B == 4 ? k_pool_q<4> : (g.B == 8 ? k_pool_q<8> : k_pool_q<16>);
+    hipLaunchKernelGGL(pool, dim3(ndtiles_alloc, g.planes), dim3(256), 0, s, (const uint8_t*)b.scaled, b.pool_pix,
                        b.pool_st, b.pool_var, b.pool_s64, (v4i*)poolQ, (uint32_t*)dflat, g, ndtiles_alloc, mode == 2 ? 1 : 0);
     FIC_LAUNCH_CHECK();
     // LDS staging of the byte copies when they fit beside the 16.6 KB of raw blocks (not at B = 16 with 8 isometries: 66 KB)
     const size_t stage_bytes = (size_t)64 * fic_q_cols_per_range(g.B, g.n_iso) * (g.n + 8);
     const int staged = stage_bytes <= 40 * 1024 ? 1 : 0;
-    hipLaunchKernelGGL(k_range_q, dim3(ngrp, g.planes), dim3(256), staged ? stage_bytes : 0, s, (const uint8_t*)b.gray, b.rng_st,
-                       (float*)rngE, b.key, (uint32_t*)theta_g, (v4i*)rngQ, (uint32_t*)rngC, g, nct_alloc, grp0, mode, staged);
+    if (g.B == 8 && mode != 1) {                               // the benchmark's shapes: copies by register permutes, 16-byte stores
+        auto rk = mode == 0 ? k_range_q8<0> : k_range_q8<2>;
+        hipLaunchKernelGGL(rk, dim3(ngrp, g.planes), dim3(256), 0, s, (const uint8_t*)b.gray, b.rng_st, (float*)rngE, b.key,
+                           (uint32_t*)theta_g, (v4i*)rngQ, (uint32_t*)rngC, g, nct_alloc, grp0);
+    } else {
+        hipLaunchKernelGGL(k_range_q, dim3(ngrp, g.planes), dim3(256), staged ? stage_bytes : 0, s, (const uint8_t*)b.gray, b.rng_st,
+                           (float*)rngE, b.key, (uint32_t*)theta_g, (v4i*)rngQ, (uint32_t*)rngC, g, nct_alloc, grp0, mode, staged);
+    }
     FIC_LAUNCH_CHECK();
     return 0;
 }

@@ -54,8 +54,14 @@ static void encode_gray_common(JNIEnv* env, jintArray argb, jint w, jint h, jint
     int Rw = 0, Rh = 0;
     int rc = fic_geometry(w, h, B, &Rw, &Rh, NULL, NULL);
     if (rc) { throw_fic(env, rc); return; }
-    const jsize nr = (jsize)Rw * Rh;
-    const jsize npix = (jsize)w * h;
+    /* sizes in 64 bits first: 3 * nr and w * h overflow a jsize for very large geometries before any comparison */
+    const int64_t nr64 = (int64_t)Rw * Rh, npix64 = (int64_t)w * h;
+    if (3 * nr64 > 2147483647LL || npix64 > 2147483647LL) {
+        throw_new(env, "java/lang/IllegalArgumentException", "fic: image too large for Java arrays (3 * N_r or w * h above 2^31 - 1)");
+        return;
+    }
+    const jsize nr = (jsize)nr64;
+    const jsize npix = (jsize)npix64;
     if ((*env)->GetArrayLength(env, argb) < npix || (*env)->GetArrayLength(env, out3N) < 3 * nr ||
         (quant3N && (*env)->GetArrayLength(env, quant3N) < 3 * nr) || (isoN && (*env)->GetArrayLength(env, isoN) < nr)) {
         throw_short(env);
@@ -106,8 +112,13 @@ JNIEXPORT void JNICALL Java_bvk_1ss19_FicNative_encodeRgb(JNIEnv* env, jclass k,
     int Rw = 0, Rh = 0;
     int rc = fic_geometry(w, h, B, &Rw, &Rh, NULL, NULL);
     if (rc) { throw_fic(env, rc); return; }
-    const jsize nr = (jsize)Rw * Rh;
-    const jsize npix = (jsize)w * h;
+    const int64_t nr64 = (int64_t)Rw * Rh, npix64 = (int64_t)w * h;
+    if (5 * nr64 > 2147483647LL || npix64 > 2147483647LL) {
+        throw_new(env, "java/lang/IllegalArgumentException", "fic: image too large for Java arrays (5 * N_r or w * h above 2^31 - 1)");
+        return;
+    }
+    const jsize nr = (jsize)nr64;
+    const jsize npix = (jsize)npix64;
     if ((*env)->GetArrayLength(env, argb) < npix || (*env)->GetArrayLength(env, out5N) < 5 * nr) {
         throw_short(env);
         return;
@@ -149,9 +160,19 @@ JNIEXPORT jintArray JNICALL Java_bvk_1ss19_FicNative_decode(JNIEnv* env, jclass 
     {
         const int isRGB = be32(buf) != 0;
         const int w = be32(buf + 4), h = be32(buf + 8);
-        int rc = fic_geometry(w, h, be32(buf + 12), NULL, NULL, NULL, NULL);
+        int Rw = 0, Rh = 0;
+        int rc = fic_geometry(w, h, be32(buf + 12), &Rw, &Rh, NULL, NULL);
         if (rc) { throw_fic(env, rc); goto done; }
-        const size_t npix = (size_t)w * (size_t)h;
+        /* the header is untrusted: before any allocation sized by it, the stream must really hold its 3 (grey) or 5 (RGB)
+         * ints per range block -- a 20-byte stream must not be able to ask for gigabytes */
+        const int64_t need = 20 + (int64_t)(isRGB ? 20 : 12) * (int64_t)Rw * (int64_t)Rh;
+        const int64_t npix64 = (int64_t)w * (int64_t)h;
+        if ((int64_t)len < need || npix64 + 2 > 2147483647LL) {
+            throw_new(env, "java/lang/IllegalArgumentException",
+                      "fic: stream shorter than its header's geometry implies (EOFException in the reference), or image too large for int[]");
+            goto done;
+        }
+        const size_t npix = (size_t)npix64;
         jfloat avg = 0;
         (*env)->GetFloatArrayRegion(env, avgError, 0, 1, &avg);
         img = (int32_t*)malloc(sizeof(int32_t) * (npix + 2));

@@ -239,6 +239,9 @@ FIC_API int fic_debug_sqrt_f64(int device, uint32_t first, uint32_t count, doubl
 /* Test hook: out[0] = the decoder's reproduction of Java's loop `avg = carry; for (i) avg += (float) vals[i];`
  * (FractalCompression.java:407) on the device. */
 FIC_API int fic_debug_float_sum(int device, float carry, const uint32_t* vals, int count, float* out);
+/* Segments (65 536 values) of this thread's last fic_debug_float_sum whose sum left its binade (or had a fractional carry-in)
+ * and therefore took the sequential-order path instead of the precomputed segment map. */
+FIC_API int fic_debug_float_sum_fallbacks(void);
 /* Test hook: fic_decode_gray_run that also reports in seq_sums how many iterations took the sequential float sum. */
 FIC_API int fic_debug_decode_gray_run(const uint8_t* run, int64_t len, int device, uint8_t* gray_out, int64_t capacity,
                                       float* avg_error_io, int* iterations, int* seq_sums);

@@ -120,3 +120,49 @@ def test_float_accumulation_scan_equals_the_sequential_loop(case):
     out = C.c_float()
     capi.check(capi.lib().fic_debug_float_sum(0, C.c_float(carry), capi.ptr(vals, C.c_uint32), vals.size, C.byref(out)))
     assert np.float32(out.value).view(np.uint32) == _seq_sum(carry, vals).view(np.uint32)
+
+
+def _seq_sum_fast(carry, vals):
+    """The same sequential float32 loop through numpy's accumulate (one rounding per add, in order)."""
+    v = np.concatenate([[np.float32(carry)], vals.astype(np.float32)]).astype(np.float32)
+    return np.add.accumulate(v, dtype=np.float32)[-1]
+
+
+@pytest.mark.parametrize("case", ["wrap32", "image16M", "stagnation", "ragged", "huge_carry", "one_segment_crossing"])
+def test_multi_workgroup_float_accumulation(case):
+    """Round 3: the sum runs on every CU (one map per 65 536-value segment and binade, then an ordered walk); only segments in
+    which the sum changes binade take the sequential-order path.  wrap32: segment totals above 2^32 at ulp 1 (the
+    tree used to wrap); image16M: as many squares as a 4096x4096 iteration; stagnation: addends below half an ulp leave the sum
+    where it is, far behind the exact prefix; ragged: a length that is no multiple of the segment; huge_carry: the static
+    avgError (FC:20) arriving large enough that nothing moves it."""
+    rng = np.random.default_rng(23)
+    carry = 0.0
+    if case == "wrap32":
+        vals = 65600 + rng.integers(0, 40, 3 * 65536 + 777)
+    elif case == "image16M":
+        vals = rng.integers(0, 256, 4096 * 4096) ** 2
+    elif case == "stagnation":
+        vals = np.concatenate([np.full(70000, 190000), np.full(2000000, 20), rng.integers(0, 70, 500000), np.full(300000, 33)])
+    elif case == "ragged":
+        vals = rng.integers(0, 195076, 5 * 65536 + 12345)
+    elif case == "huge_carry":
+        carry = 3.0e13
+        vals = rng.integers(0, 195076, 200000)
+    else:
+        vals = np.concatenate([np.full(16000, 1000), rng.integers(0, 5, 30000), np.full(10000, 1700)])
+    vals = np.ascontiguousarray(vals, np.uint32)
+    out = C.c_float()
+    capi.check(capi.lib().fic_debug_float_sum(0, C.c_float(carry), capi.ptr(vals, C.c_uint32), vals.size, C.byref(out)))
+    want = _seq_sum_fast(carry, vals)
+    assert np.float32(out.value).view(np.uint32) == np.float32(want).view(np.uint32), (out.value, want)
+    nseg = (vals.size + 65535) // 65536
+    fb = capi.lib().fic_debug_float_sum_fallbacks()
+    assert fb <= min(nseg, 24), f"{fb} of {nseg} segments took the sequential-order path"
+    if case == "image16M":
+        assert nseg == 256 and 1 <= fb <= 24
+
+
+def test_accumulate_helper_is_the_sequential_loop():
+    rng = np.random.default_rng(1)
+    v = np.ascontiguousarray(rng.integers(0, 195076, 50000), np.uint32)
+    assert _seq_sum_fast(0.25, v).view(np.uint32) == _seq_sum(0.25, v).view(np.uint32)

@@ -7,10 +7,11 @@ import numpy as np
 import pytest
 
 import fic_amd
+from fic_amd import capi
 from fic_amd import synth
 from conftest import GOLDEN, same_f32
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not capi.has_xcheck(), reason="library built with FIC_BUILD_XCHECK=0: no sweep 3 / 4")]
 
 IMAGES = {
     "lena64": np.load(os.path.join(GOLDEN, "lena64.npy")),
