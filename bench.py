@@ -95,8 +95,9 @@ def kernel_name(kind, B, n_iso, chunks=1):
     if kind == 4:
         return "k_sweep_mfma" + ("" if n_iso == 8 else "1"), "i8"
     if kind == 6:     # k_sweep_q<NK, MODE, MULTI>: NK = n/16 MFMA steps, MODE 0 = 1 isometry, 1 = 8 isometries (B = 4), 2 = 8 isometries
-        # folded; MULTI: the launch has more than one pool chunk
-        return f"k_sweep_q<{B * B // 16}, {0 if n_iso == 1 else (1 if B == 4 else 2)}, {'true' if chunks > 1 else 'false'}>", "f16"
+        # folded; MULTI: the launch has more than one pool chunk.  1 isometry at B = 8 / 16: k_sweep_q16<NK, MULTI> (16x16x32 MFMA)
+        multi = 'true' if chunks > 1 else 'false'     # (1 isometry on LARGE pools at B = 8 / 16 runs k_sweep_q16: Encoder.last_kernel() knows)
+        return f"k_sweep_q<{B * B // 16}, {0 if n_iso == 1 else (1 if B == 4 else 2)}, {multi}>", "f16"
     return SWEEP_KINDS.get(kind, ("k_sweep_fast", None))[0], None
 
 
@@ -506,6 +507,7 @@ def roofline_blocks(args, run, info, avg_ms, sweep_n, clock_ghz):
     n, Nd = B * B, run.Nd
     kind = info["sweep_kind"]
     kname, operand = kernel_name(kind, B, n_iso, info["chunks"])
+    kname = run.core.last_kernel()                         # the library knows which instantiation it launched (k_sweep_q / k_sweep_q16)
     pair_evals = float(run.ranges_per_step_rank) * Nd * n_iso
     # SURVEY 8(d)'s byte model: n+8 bytes per (range, domain) pair, one pool read per range block
     alg_bytes = float(run.ranges_per_step_rank) * Nd * (n + 8)
@@ -705,7 +707,7 @@ def main():
             "scaling": scaling, "vs_baseline": None, "dtype": "u8",
             "dtype_detail": {"bf16": "centred u8 pixels as exact bf16, v_mfma_f32_32x32x16_bf16 -> exact f32 covariances, f32 prune test, f64/f32 Java epilogue",
                              "i8": "u8 pixels shifted to i8, v_mfma_i32_32x32x32_i8 -> exact i32 covariances, same epilogue",
-                             "f16": "centred u8 range pixels (exact f16) x normalised domain pixels (f16), v_mfma_f32_32x32x16_f16 -> "
+                             "f16": "centred u8 range pixels (exact f16) x normalised domain pixels (f16), v_mfma_f32_32x32x16_f16 (1 isometry at B = 8 / 16: 16x16x32) -> "
                                     "|cov|/sqrt(var) within a proven bound = the prune test; surviving pairs: exact integer covariance "
                                     "(v_dot4_u32_u8) + f64/f32 Java epilogue",
                              None: "u8 pixels, v_dot4_u32_u8 / v_dot2c_i32_i16 -> exact i32 covariances, f32 prune test, f64/f32 Java epilogue"}[operand],
@@ -869,11 +871,12 @@ def single_image(fic_amd, torch, img, B, n_iso, device, sweep, reps=200):
         enc.encode(0, -1, s)
     sw_ms, sw_n = enc.sweep_time(reset=True)
     info = enc.info()
+    kname_single = enc.last_kernel()
     nr = enc.n_ranges
     enc.close()
     return {"workload": f"one {W}x{H} synthetic grey U image, B={B}, full search, {n_iso} iso (BASELINE config 2 literally)",
             "ms": ms, "matches_per_s": nr / (ms * 1e-3), "latency_ms": lat[len(lat) // 2],
-            "sweep_ms": sw_ms / max(sw_n, 1), "kernel": kernel_name(info["sweep_kind"], B, n_iso, info["chunks"])[0], "pool_chunks": info["chunks"],
+            "sweep_ms": sw_ms / max(sw_n, 1), "kernel": kname_single, "pool_chunks": info["chunks"],
             "note": "ms: HIP events around 200 back-to-back encodes (pool build + range prep + sweep + finalise each); "
                     "latency_ms: median host time of encode + sync"}
 

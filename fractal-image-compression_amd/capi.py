@@ -104,6 +104,7 @@ def lib():
         "fic_ctx_sweep_time": (C.c_int, [vp, C.POINTER(C.c_double), ip, C.c_int]),
         "fic_ctx_info": (C.c_int, [vp, ip]),
         "fic_sweep_ranges_per_pool_read": (C.c_int, [C.c_int, C.c_int, C.c_int]),
+        "fic_ctx_last_kernel": (C.c_int, [vp, C.c_char_p, C.c_int]),
         "fic_ctx_sweep_stats": (C.c_int, [vp, C.POINTER(C.c_uint64), C.c_int]),
         "fic_debug_rccl_selftest": (C.c_int, [C.c_int]),
         "fic_debug_gather_fallbacks": (C.c_int, []),

@@ -741,6 +741,9 @@ int fic_ctx_set_option(fic_ctx* c, const char* name, int value)
     } else if (!strcmp(name, "chunks")) {
         if (value < 0) return fail(FIC_E_ARGUMENT, "chunks must be >= 0");
         c->opt_chunks = value;
+    } else if (!strcmp(name, "q_shape")) {             // MFMA shape of the 1-isometry k_sweep_q at B = 8 / 16 (tests, A/B runs)
+        if (value < 0 || value > 2) return fail(FIC_E_ARGUMENT, "q_shape must be 0 (by pool size), 1 (16x16x32) or 2 (32x32x16)");
+        c->g.q_shape = value;
     } else if (!strcmp(name, "q_noflag")) {            // diagnostic: k_sweep_q without any flagged tile (wrong codebooks): its floor
         c->opt_noflag = value ? 1 : 0;
     } else if (!strcmp(name, "time_sweep")) {
@@ -796,6 +799,26 @@ int fic_ctx_info(fic_ctx* c, int* out10)
     const FicGeom& g = c->g;
     int v[10] = {g.Rw, g.Rh, g.Nr, g.Dw, g.Dh, g.Nd, g.NR, g.tiles, c->last_chunks, c->last_kind};
     memcpy(out10, v, sizeof(v));
+    return FIC_OK;
+}
+
+int fic_ctx_last_kernel(fic_ctx* c, char* out, int capacity)
+{
+    if (!c || !out || capacity < 1) return fail(FIC_E_ARGUMENT, "fic_ctx_last_kernel: bad argument");
+    const FicGeom& g = c->g;
+    const int NK = g.n / 16, kind = c->last_kind;
+    const char* multi = c->last_chunks > 1 ? "true" : "false";
+    char buf[96];
+    if (kind == 6 && fic_q_shape16(g)) snprintf(buf, sizeof(buf), "k_sweep_q16<%d, %s>", NK, multi);
+    else if (kind == 6) snprintf(buf, sizeof(buf), "k_sweep_q<%d, %d, %s>", NK, g.n_iso == 1 ? 0 : (g.B == 4 ? 1 : 2), multi);
+    else if (kind == 5) snprintf(buf, sizeof(buf), "k_sweep_d4");
+    else if (kind == 2) snprintf(buf, sizeof(buf), "k_sweep_fast");
+    else if (kind == 1) snprintf(buf, sizeof(buf), "k_sweep_generic");
+    else if (kind == 3 || kind == 4) {
+        const bool bf16 = kind == 3 && (g.B <= 8 || g.n_iso == 8);
+        snprintf(buf, sizeof(buf), "%s%s", bf16 ? "k_sweep_bf16" : "k_sweep_mfma", g.n_iso == 8 ? "" : (bf16 ? "_1" : "1"));
+    } else snprintf(buf, sizeof(buf), "(none)");
+    snprintf(out, (size_t)capacity, "%s", buf);
     return FIC_OK;
 }
 

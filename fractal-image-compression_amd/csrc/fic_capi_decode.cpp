@@ -62,9 +62,9 @@ static thread_local int g_last_sum_fallbacks = 0;
 
 extern "C" {
 
-// Runs the reconstruction loop on the device.  Iterations are enqueued in groups of 8 and the
-// per-plane loop state is read back after each group (a converging decode takes 6-7 iterations),
-// so there is one host sync per group, none per iteration.
+// Runs the reconstruction loop on the device.  The first 8 iterations are enqueued in one go, later ones in pairs, and the
+// per-plane loop state is read back after each group (a converging decode takes 6-9 iterations): one host sync per
+// group, none per iteration; iterations enqueued behind the last one exit at once.
 //   d_state [planes], d_sqbuf u32 [planes][W*H]: scratch of the caller
 static int run_decode_loop(const FicGeom& g, uint8_t* d_scaled, uint8_t* d_image, const int32_t* d_qrows,
                            const int32_t* d_iso, FicDecodeState* d_state, uint32_t* d_sqbuf, const float* avg_in,
@@ -83,7 +83,8 @@ static int run_decode_loop(const FicGeom& g, uint8_t* d_scaled, uint8_t* d_image
             rc = fail(FIC_E_HIP, "decode iteration launch failed");
             break;
         }
-        if ((counter & 7) == 7 || counter == 49) {
+        // a converging decode takes 6-9 iterations: look at the loop state after 8, then after every second iteration
+        if (counter == 7 || (counter > 7 && (counter & 1)) || counter == 49) {
             e = hipMemcpyAsync(st.data(), d_state, P * sizeof(FicDecodeState), hipMemcpyDeviceToHost, s);
             if (e == hipSuccess) e = hipStreamSynchronize(s);
             if (e != hipSuccess) { rc = fail(FIC_E_HIP, "decode readback: %s", hipGetErrorString(e)); break; }

@@ -24,41 +24,67 @@
 //            (kept in `sqbuf` in Java's visiting order) exactly as FC:407 does, one float add per pixel in that order
 //            (java_float_sum: a parallel scan over parity-dependent rounding maps, same bits as the sequential loop).
 // ---------------------------------------------------------------------------------------------
+// One thread = one pixel ROW of one range block (B pixels): the codebook row, its fit and its domain block are looked up once
+// per B pixels, the image row is one B-byte load + store, the squares one contiguous run of `sqbuf`.  Threads are ordered
+// (block row, pixel row, block column): neighbours in a wave touch neighbouring bytes of the same image row.
+template <int B>
 __global__ __launch_bounds__(256) void k_decode_paint(const uint8_t* __restrict__ scaled, uint8_t* __restrict__ image,
                                                       const int32_t* __restrict__ qrows, const int32_t* __restrict__ iso,
                                                       FicDecodeState* __restrict__ state, uint32_t* __restrict__ sqbuf,
                                                       int counter, FicGeom g)
 {
-    int x = blockIdx.x * 256 + threadIdx.x;
-    int y = blockIdx.y;
-    int plane = blockIdx.z;
+    const int plane = blockIdx.y;
     FicDecodeState* st = state + plane;
     if (st->done) return;                                  // uniform per plane
+    const int t = blockIdx.x * 256 + threadIdx.x;          // (by * B + ry) * Rw + bx
     unsigned long long sq = 0;
-    if (x < g.W) {
-        int j = (y / g.B) * g.Rw + (x / g.B);
-        int rx = x % g.B, ry = y % g.B;
-        size_t o = (size_t)plane * g.Nr + j;
-        int wloc = qrows[3 * o + 0];
-        float a = __fdiv_rn((float)qrows[3 * o + 1], 100.0f);
-        float b = (float)qrows[3 * o + 2];
-        bool ok = wloc >= 0 && wloc < g.wK * g.wK;
-        int gi = ok ? window_to_global(g, j, wloc) : 0;
+    if (t < g.Nr * B) {
+        const int bx = t % g.Rw, row = t / g.Rw;           // row = by * B + ry = the image row
+        const int ry = row % B, by = row / B;
+        const int j = by * g.Rw + bx;
+        const size_t o = (size_t)plane * g.Nr + j;
+        const int wloc = qrows[3 * o + 0];
+        const float a = __fdiv_rn((float)qrows[3 * o + 1], 100.0f);
+        const float b = (float)qrows[3 * o + 2];
+        const bool ok = wloc >= 0 && wloc < g.wK * g.wK;
+        const int gi = ok ? window_to_global(g, j, wloc) : 0;
+        uint8_t* prow = image + (size_t)plane * g.W * g.H + (size_t)row * g.W + bx * B;
+        uint32_t* srow = sqbuf + (size_t)plane * g.W * g.H + ((size_t)j * B + ry) * B;   // Java's visiting order (FC:385-389)
+        uint32_t old[B / 4], neu[B / 4], sqv[B];
+        __builtin_memcpy(old, prow, B);
         if (!ok || gi < 0 || gi >= g.Nd) {
             st->bad_index = 1;                             // Java: ArrayIndexOutOfBoundsException at FC:394
+#pragma unroll
+            for (int x = 0; x < B; x++) sqv[x] = 0u;
         } else {
-            int src = iso ? iso_source(iso[o], g.B, rx, ry) : rx + ry * g.B;
-            int c = gi % g.Dw, r = gi / g.Dw;
-            int domain = scaled[(size_t)plane * g.Ws * g.Hs + (size_t)(r * g.abstand + src / g.B) * g.Ws + c * g.abstand + src % g.B];
-            int value = java_f2i(__fadd_rn(__fmul_rn(a, (float)domain), b));
-            value = value < 0 ? 0 : (value > 255 ? 255 : value);
-            size_t p = (size_t)plane * g.W * g.H + (size_t)y * g.W + x;
-            int d = (int)image[p] - value;
-            image[p] = (uint8_t)value;
-            sq = (unsigned long long)(d * d);
+            const int c = gi % g.Dw, r = gi / g.Dw;
+            const uint8_t* dom = scaled + (size_t)plane * g.Ws * g.Hs + (size_t)(r * g.abstand) * g.Ws + c * g.abstand;
+            uint8_t dpx[B];
+            const int k = iso ? iso[o] : 0;
+            if (k == 0) {
+                __builtin_memcpy(dpx, dom + (size_t)ry * g.Ws, B);       // the block's row ry: B consecutive scaled pixels
+            } else {
+                int ax, bx_, cx, ay, by_, cy;
+                iso_affine(k, B - 1, ax, bx_, cx, ay, by_, cy);          // source (sx, sy) = (ax x + bx y + cx, ay x + by y + cy)
+                const int s0 = (cy + by_ * ry) * g.Ws + cx + bx_ * ry, sx = ay * g.Ws + ax;
+#pragma unroll
+                for (int x = 0; x < B; x++) dpx[x] = dom[s0 + sx * x];
+            }
+#pragma unroll
+            for (int q = 0; q < B / 4; q++) neu[q] = 0u;
+#pragma unroll
+            for (int x = 0; x < B; x++) {
+                int value = java_f2i(__fadd_rn(__fmul_rn(a, (float)dpx[x]), b));
+                value = value < 0 ? 0 : (value > 255 ? 255 : value);
+                const int dd = (int)((old[x >> 2] >> (8 * (x & 3))) & 0xffu) - value;
+                neu[x >> 2] |= (uint32_t)value << (8 * (x & 3));
+                sqv[x] = (uint32_t)(dd * dd);
+                sq += sqv[x];
+            }
+            __builtin_memcpy(prow, neu, B);
         }
-        // Java's visiting order: range blocks row-major, pixels row-major inside a block (FC:385-389)
-        sqbuf[(size_t)plane * g.W * g.H + ((size_t)j * g.B + ry) * g.B + rx] = (uint32_t)sq;
+#pragma unroll
+        for (int q = 0; q < B / 4; q++) *(uint4*)(srow + 4 * q) = make_uint4(sqv[4 * q], sqv[4 * q + 1], sqv[4 * q + 2], sqv[4 * q + 3]);
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) sq += __shfl_xor(sq, off, 64);
@@ -66,8 +92,8 @@ __global__ __launch_bounds__(256) void k_decode_paint(const uint8_t* __restrict_
     if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = sq;
     __syncthreads();
     if (threadIdx.x == 0) {
-        unsigned long long t = s_part[0] + s_part[1] + s_part[2] + s_part[3];
-        if (t) atomicAdd(&st->ssd[counter], t);
+        unsigned long long tot = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+        if (tot) atomicAdd(&st->ssd[counter], tot);
     }
 }
 
@@ -114,21 +140,33 @@ __device__ __forceinline__ void run_maps(const uint4 (&v4)[FIC_SUM_RUN / 4], int
 }
 __device__ float java_float_sum(float carry, const uint32_t* __restrict__ d, int count)
 {
-    __shared__ uint32_t f0[FIC_SUM_THREADS], f1[FIC_SUM_THREADS];      // maps, composed in place by the tree
-    __shared__ uint32_t g0[FIC_SUM_THREADS], g1[FIC_SUM_THREADS];      // the per-thread maps, kept for a block that leaves the binade
+    __shared__ uint32_t pm[FIC_SUM_THREADS];                           // m after the runs 0 .. t (saturated): the inclusive scan applied to m
+    __shared__ uint32_t wv0[FIC_SUM_THREADS / 64], wv1[FIC_SUM_THREADS / 64];
+    __shared__ uint32_t stage[FIC_SUM_THREADS];                        // values staged for thread 0's plain float adds
     __shared__ float s_sum;
-    __shared__ int s_pos, s_k;
+    __shared__ int s_pos, s_k, s_tt, s_more;
     __shared__ uint32_t s_m;
-    const int t = threadIdx.x;
-    if (t == 0) {
-        float sum = carry;
-        int i = 0;
-        // fractional carry-in: plain adds until the sum is integer-valued (and the position 16-byte aligned for the vector loads)
-        while (i < count && (sum != truncf(sum) || sum < 0.0f || (i & 3))) sum = __fadd_rn(sum, (float)d[i++]);
-        s_sum = sum;
-        s_pos = i;
-    }
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    // Head: while the carry-in still has a fractional part (or the position is not 16-byte aligned) the adds are plain float adds
+    // in order -- by thread 0, out of LDS, a staged chunk at a time (a dependent global load per add costs a microsecond each,
+    // and a fractional carry lives until the sum passes 2^23: thousands of adds).
+    if (t == 0) { s_sum = carry; s_pos = 0; s_more = 1; }
     __syncthreads();
+    while (s_more) {                                                    // uniform
+        const int p0 = s_pos;
+        stage[t] = p0 + t < count ? d[p0 + t] : 0u;
+        __syncthreads();
+        if (t == 0) {
+            float sum = s_sum;
+            int i = p0;
+            const int lim = p0 + FIC_SUM_THREADS < count ? p0 + FIC_SUM_THREADS : count;
+            while (i < lim && (sum != truncf(sum) || sum < 0.0f || (i & 3))) sum = __fadd_rn(sum, (float)stage[i++ - p0]);
+            s_sum = sum;
+            s_pos = i;
+            s_more = (i == lim && i < count && (sum != truncf(sum) || sum < 0.0f)) ? 1 : 0;   // chunk used up, still fractional
+        }
+        __syncthreads();
+    }
     for (;;) {
         const int base = s_pos;
         if (base >= count) break;
@@ -139,6 +177,7 @@ __device__ float java_float_sum(float carry, const uint32_t* __restrict__ d, int
             if (sum >= 16777216.0f) k = (int)((__float_as_uint(sum) >> 23) & 0xFF) - 127 - 23;
             s_k = k;
             s_m = k < FIC_SUM_KMAPS ? (uint32_t)(sum * __uint_as_float((uint32_t)(127 - k) << 23)) : 0u;   // exact power-of-two scaling
+            s_tt = FIC_SUM_THREADS;
         }
         __syncthreads();
         const int k = s_k;
@@ -158,45 +197,46 @@ __device__ float java_float_sum(float carry, const uint32_t* __restrict__ d, int
             }
             run_maps(v4, k, a0, a1);
         }
-        f0[t] = a0;
-        f1[t] = a1;
-        g0[t] = a0;
-        g1[t] = a1;
-        __syncthreads();
-        for (int stride = 1; stride < FIC_SUM_THREADS; stride <<= 1) {
-            if ((t & (2 * stride - 1)) == 0) {
-                uint32_t l0 = f0[t], l1 = f1[t];
-                map_compose(l0, l1, f0[t + stride], f1[t + stride]);
-                f0[t] = l0;
-                f1[t] = l1;
-            }
-            __syncthreads();
+        // ordered INCLUSIVE scan of the 1024 run maps: thread t ends with the map of the runs 0 .. t (lanes of a wave by
+        // shuffles, then the 16 wave totals)
+#pragma unroll
+        for (int stride = 1; stride < 64; stride <<= 1) {
+            uint32_t l0 = __shfl_up(a0, stride, 64), l1 = __shfl_up(a1, stride, 64);
+            if (lane >= stride) { map_compose(l0, l1, a0, a1); a0 = l0; a1 = l1; }
         }
-        if (t == 0) {
-            const uint32_t m = s_m;
-            int end = base + FIC_SUM_THREADS * FIC_SUM_RUN;
-            if (end > count) end = count;
-            const uint32_t inc = (m & 1u) ? f1[0] : f0[0];            // saturated at 2^24: m + inc < 2^24 only for true increments
-            const unsigned long long mn = (unsigned long long)m + inc;
-            if (mn < 16777216ull) {
-                s_sum = (float)(uint32_t)mn * __uint_as_float((uint32_t)(127 + k) << 23);     // exact: m' < 2^24
-            } else {
-                // The sum leaves the binade inside this block.  The per-thread maps are valid up to the thread in whose
-                // run that happens: apply them one by one, add that one run in plain float, and restart behind it (the
-                // maps of the threads after it were folded with the old ulp).
-                uint32_t mm = m;
-                int tt = 0;
-                for (; tt < FIC_SUM_THREADS; tt++) {
-                    const unsigned long long nx = (unsigned long long)mm + ((mm & 1u) ? g1[tt] : g0[tt]);
-                    if (nx >= 16777216ull) break;
-                    mm = (uint32_t)nx;
-                }
-                float sum = (float)mm * __uint_as_float((uint32_t)(127 + k) << 23);
-                int i = base + tt * FIC_SUM_RUN;
-                end = i + FIC_SUM_RUN < end ? i + FIC_SUM_RUN : end;
-                for (; i < end; i++) sum = __fadd_rn(sum, (float)d[i]);
+        if (lane == 63) { wv0[wave] = a0; wv1[wave] = a1; }
+        __syncthreads();
+        if (wave > 0) {
+            uint32_t l0 = wv0[0], l1 = wv1[0];
+            for (int w = 1; w < wave; w++) map_compose(l0, l1, wv0[w], wv1[w]);
+            map_compose(l0, l1, a0, a1);
+            a0 = l0;
+            a1 = l1;
+        }
+        const uint32_t m = s_m;
+        const uint32_t inc = (m & 1u) ? a1 : a0;                        // saturated at 2^24: m + inc < 2^24 only for true increments
+        const bool over = inc >= FIC_SUM_SAT || m + inc >= FIC_SUM_SAT;
+        pm[t] = over ? FIC_SUM_SAT : m + inc;
+        if (over) atomicMin(&s_tt, t);                                  // the first run in which the sum leaves the binade
+        __syncthreads();
+        const int tt = s_tt;
+        int end = base + FIC_SUM_THREADS * FIC_SUM_RUN;
+        if (end > count) end = count;
+        if (tt < FIC_SUM_THREADS) {
+            // The sum leaves the binade inside run tt: the maps are valid up to the run before it; that one run is added in plain
+            // float (staged through LDS), and the scan restarts behind it with the new ulp.
+            const int r0 = base + tt * FIC_SUM_RUN;
+            if (t < FIC_SUM_RUN) stage[t] = r0 + t < count ? d[r0 + t] : 0u;
+            __syncthreads();
+            if (t == 0) {
+                float sum = (float)(tt == 0 ? m : pm[tt - 1]) * __uint_as_float((uint32_t)(127 + k) << 23);
+                const int rend = r0 + FIC_SUM_RUN < end ? r0 + FIC_SUM_RUN : end;
+                for (int i = r0; i < rend; i++) sum = __fadd_rn(sum, (float)stage[i - r0]);
                 s_sum = sum;
+                s_pos = rend;
             }
+        } else if (t == 0) {
+            s_sum = (float)pm[FIC_SUM_THREADS - 1] * __uint_as_float((uint32_t)(127 + k) << 23);     // exact: m' < 2^24
             s_pos = end;
         }
         __syncthreads();
@@ -471,7 +511,8 @@ int fic_launch_decode_iteration(uint8_t* scaled, uint8_t* image, const int32_t* 
                                 FicDecodeState* state, uint32_t* sqbuf, int counter, const FicGeom& g, hipStream_t s)
 {
     if (fic_launch_scale(image, scaled, g, s)) return -1;      // FC:382 -> createCodebuch -> scaleImage
-    hipLaunchKernelGGL(k_decode_paint, dim3((g.W + 255) / 256, g.H, g.planes), dim3(256), 0, s, scaled, image, qrows, iso,
+    auto paint = g.B == 4 ? k_decode_paint<4> : (g.B == 8 ? k_decode_paint<8> : k_decode_paint<16>);
+    hipLaunchKernelGGL(paint, dim3((g.Nr * g.B + 255) / 256, g.planes), dim3(256), 0, s, scaled, image, qrows, iso,
                        state, sqbuf, counter, g);
     FIC_LAUNCH_CHECK();
     return fic_launch_decode_step(state, sqbuf, counter, g.W * g.H, g.planes, s);

@@ -18,6 +18,7 @@ struct FicGeom {
     int Nr_pad;              // tiles * 64 * NR
     int Nd_pad;              // Nd + FIC_POOL_PAD (zero tail so the prefetch may over-read)
     int full;                // 1 when wK == Dw == Dh (window origin is (0,0) for every range)
+    int q_shape;             // MFMA shape of the 1-isometry k_sweep_q at B = 8 / 16: 0 = by pool size, 1 = 16x16x32, 2 = 32x32x16 (option "q_shape")
 };
 
 #define FIC_POOL_PAD 8

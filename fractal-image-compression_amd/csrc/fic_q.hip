@@ -80,6 +80,25 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 __host__ __device__ constexpr int fic_q_ctw(int NK) { return NK == 4 ? FIC_Q_CTW_B8 : (NK < 4 ? FIC_Q_CTW_B4 : 2); }   // column tiles (x32 range copies) per wave
 #define FIC_Q_UNROLL 2                     // domain tiles per iteration of the sweep loop (two fragment buffers swap roles)
 
+#ifndef FIC_Q_SHAPE16
+#define FIC_Q_SHAPE16 1                    // 1 isometry at B = 8 / 16: v_mfma_f32_16x16x32_f16 (k_sweep_q16) instead of 32x32x16
+#endif
+// Which 8 consecutive operand elements slot (s, lane) of a 32-row (or 32-column) fragment tile of NK slots holds.
+//   shape 0, v_mfma_f32_32x32x16:  row = lane & 31,                       elements [16 s + 8 (lane >> 5), +8)
+//   shape 1, v_mfma_f32_16x16x32:  [sub-tile s / KS][K step s % KS], KS = NK / 2:
+//                                  row = 16 (s / KS) + (lane & 15),       elements [32 (s % KS) + 8 (lane >> 4), +8)
+__device__ __forceinline__ void frag_slot(int shape16, int NK, int s, int lane, int& row, int& p0)
+{
+    if (!shape16) {
+        row = lane & 31;
+        p0 = 16 * s + 8 * (lane >> 5);
+    } else {
+        const int KS = NK >> 1;
+        row = 16 * (s / KS) + (lane & 15);
+        p0 = 32 * (s % KS) + 8 * (lane >> 4);
+    }
+}
+
 // two floats -> packed f16 pair (round to nearest even), element 0 in the low half
 __device__ __forceinline__ int f16_pair(float lo, float hi)
 {
@@ -99,7 +118,7 @@ template <int B>
 __global__ __launch_bounds__(256) void k_pool_q(const uint8_t* __restrict__ scaled, uint8_t* __restrict__ pool_pix,
                                                 FicDomStat* __restrict__ pool_st, uint32_t* __restrict__ pool_var,
                                                 double* __restrict__ pool_s64, v4i* __restrict__ poolQ,
-                                                uint32_t* __restrict__ dflat, FicGeom g, int ndtiles_alloc, int folded)
+                                                uint32_t* __restrict__ dflat, FicGeom g, int ndtiles_alloc, int folded, int shape16)
 {
     __shared__ __attribute__((aligned(16))) uint8_t pix[32][256 + 16];
     __shared__ int s_sum[32][16], s_sq[32][16];
@@ -166,13 +185,15 @@ __global__ __launch_bounds__(256) void k_pool_q(const uint8_t* __restrict__ scal
     // (c) fragments
     for (int t = threadIdx.x; t < NK * 64; t += 256) {
         const int lane = t & 63, m = t >> 6;
-        const int i = lane & 31, h = lane >> 5;
+        int i, pos0;
+        frag_slot(shape16, NK, m, lane, i, pos0);      // (the folded form below is always shape 0)
+        const int h = lane >> 5;
         const float w = s_w[i];
         const int dM = s_mean[i];
         v4i v;
         // (8 consecutive pixels = one 8-byte LDS read; rows of pix are 272 bytes apart, positions are multiples of 8)
         if (!folded) {
-            const uint2 pw = *(const uint2*)&pix[i][16 * m + 8 * h];
+            const uint2 pw = *(const uint2*)&pix[i][pos0];
             int px[8];
 #pragma unroll
             for (int u = 0; u < 8; u++) px[u] = (int)(((u < 4 ? pw.x : pw.y) >> (8 * (u & 3))) & 0xffu);
@@ -215,7 +236,7 @@ __global__ __launch_bounds__(256) void k_range_q(const uint8_t* __restrict__ gra
                                                  float* __restrict__ rngE, unsigned long long* __restrict__ key,
                                                  uint32_t* __restrict__ theta_g, v4i* __restrict__ rngQ,
                                                  uint32_t* __restrict__ rngC, FicGeom g, int nct_alloc, int grp0, int mode,
-                                                 int staged)
+                                                 int staged, int shape16)
 {
     __shared__ __attribute__((aligned(16))) uint8_t blk[64 * (256 + 4)];
     extern __shared__ __attribute__((aligned(16))) uint8_t cpy[];   // staged: [columns][n + 8] the copies as bytes
@@ -303,7 +324,9 @@ __global__ __launch_bounds__(256) void k_range_q(const uint8_t* __restrict__ gra
     // fragments: thread = (column tile, m, lane)
     for (int t = threadIdx.x; t < (cols / 32) * NK * 64; t += 256) {
         const int lane = t & 63, m = (t >> 6) % NK, ctl = (t >> 6) / NK;
-        const int col = ctl * 32 + (lane & 31), h = lane >> 5;
+        int c32, pos0;
+        frag_slot(shape16, NK, m, lane, c32, pos0);    // (shape 1 only with mode 0)
+        const int col = ctl * 32 + c32, h = lane >> 5;
         const int l = col >> lgc, c = col & (cpr - 1);
         const int rM = s_rM[l];
         const bool real = j0 + l < g.Nr;
@@ -311,7 +334,7 @@ __global__ __launch_bounds__(256) void k_range_q(const uint8_t* __restrict__ gra
         if (staged) {
             const uint8_t* cp = cpy + col * cstride;
             if (mode != 2) {
-                const uint2 w = *(const uint2*)(cp + 16 * m + 8 * h);
+                const uint2 w = *(const uint2*)(cp + pos0);
 #pragma unroll
                 for (int u = 0; u < 8; u++) a[u] = (int)(((u < 4 ? w.x : w.y) >> (8 * (u & 3))) & 0xffu) - rM;
             } else {
@@ -332,7 +355,7 @@ __global__ __launch_bounds__(256) void k_range_q(const uint8_t* __restrict__ gra
             const int s0 = cx + cy * B, sx = ax + ay * B, sy = bx + by * B;
             const uint8_t* b = blk + l * stride;
             if (mode != 2) {
-                const int p0 = 16 * m + 8 * h;
+                const int p0 = pos0;
 #pragma unroll
                 for (int u = 0; u < 8; u++) {
                     const int p = p0 + u;
@@ -399,7 +422,7 @@ template <int MODE>
 __global__ __launch_bounds__(256) void k_range_q8(const uint8_t* __restrict__ gray, FicRngStat* __restrict__ rng_st,
                                                   float* __restrict__ rngE, unsigned long long* __restrict__ key,
                                                   uint32_t* __restrict__ theta_g, v4i* __restrict__ rngQ,
-                                                  uint32_t* __restrict__ rngC, FicGeom g, int nct_alloc, int grp0)
+                                                  uint32_t* __restrict__ rngC, FicGeom g, int nct_alloc, int grp0, int shape16)
 {
     constexpr int B = 8, n = 64, DW = 16, NK = 4, CPR = MODE == 0 ? 1 : 4, STR = 80;     // STR: LDS bytes per block / copy (16-byte aligned rows)
     __shared__ __attribute__((aligned(16))) uint8_t blk[64 * STR];
@@ -485,14 +508,16 @@ __global__ __launch_bounds__(256) void k_range_q8(const uint8_t* __restrict__ gr
     // fragments: thread = (column tile, m, lane), exactly as the staged branch of k_range_q
     for (int t = threadIdx.x; t < (cols / 32) * NK * 64; t += 256) {
         const int lane = t & 63, m = (t >> 6) % NK, ctl = (t >> 6) / NK;
-        const int col = ctl * 32 + (lane & 31), h = lane >> 5;
+        int c32, pos0;
+        frag_slot(MODE == 0 ? shape16 : 0, NK, m, lane, c32, pos0);
+        const int col = ctl * 32 + c32, h = lane >> 5;
         const int l = col / CPR;
         const int rM = s_rM[l];
         const bool real = j0 + l < g.Nr;
         const uint8_t* cp = cps + col * STR;
         int a[8];
         if constexpr (MODE != 2) {
-            const uint2 w = *(const uint2*)(cp + 16 * m + 8 * h);
+            const uint2 w = *(const uint2*)(cp + pos0);
 #pragma unroll
             for (int u = 0; u < 8; u++) a[u] = (int)(((u < 4 ? w.x : w.y) >> (8 * (u & 3))) & 0xffu) - rM;
         } else {
@@ -924,6 +949,199 @@ __global__ __launch_bounds__(64 * FIC_Q_WPG, NK == 4 ? FIC_Q_WAVES_B8 : (NK < 4 
 }
 
 // ---------------------------------------------------------------------------------------------
+// k_sweep_q16<NK, MULTI> : the 1-isometry sweep (the reference algorithm, MODE 0) at B = 8 / 16 on v_mfma_f32_16x16x32_f16.
+// Same search, same queue, same exact path (q_flush) as k_sweep_q<NK, 0>; what changes is the matrix instruction and with it
+// the lane layout.  Why: the dense sweeps are power-limited (the chip holds 1.6-1.75 GHz under 32x32x16), and it holds a
+// higher clock under the 16x16x32 shape at the same work per output -- tools/mfma_shape.hip, this kernel's fast path on random
+// data: 1.93-1.96 GHz against 1.60-1.76, 7-15 % less time (profiles/r03g_mfma_shape_16x16x32_vs_32x32x16_microbench.txt).
+//   unit = 32 domain blocks x 16 range columns: 2 row tiles x KS = NK/2 chained MFMAs of K = 32 -> two 4-element accumulators;
+//   lane (c = lane & 15, g = lane >> 4) holds column c against rows 16 rt + 4 g + i (rt = accumulator, i = element):
+//   ONE column per lane and unit, so theta stays one VGPR per unit (2 CTW units per wave); the four lanes of a column
+//   (g = 0..3) share raised values by v_permlane16_swap + v_permlane32_swap.  Epilogue per unit: 4 v_max3 + compare.
+//   Fragments come in the [sub-tile][K step][lane] order of frag_slot(shape 1) from k_pool_q / k_range_q*.
+// ---------------------------------------------------------------------------------------------
+typedef float v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ v4f mfma16_f16(v4i a, v4i b, v4f c)
+{
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ float max8_abs(const v4f& x0, const v4f& x1)
+{
+    const float m0 = max3f(fabsf(x0[0]), fabsf(x0[1]), fabsf(x0[2])), m1 = max3f(fabsf(x0[3]), fabsf(x1[0]), fabsf(x1[1]));
+    return max3f(m0, m1, max3f(fabsf(x1[2]), fabsf(x1[3]), 0.0f));
+}
+// maximum over the four lanes (row groups g = 0..3) that hold the same column.  Every lane of the wave must be active.
+__device__ __forceinline__ float q16_share_max(float v)
+{
+    const uint32_t u = __float_as_uint(v);
+    const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);      // rows 0/1 and 2/3 of 16 lanes exchanged
+    const float w = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    const uint32_t uw = __float_as_uint(w);
+    const auto q = __builtin_amdgcn_permlane32_swap(uw, uw, false, false);    // the two halves
+    return fmaxf(__uint_as_float(q[0]), __uint_as_float(q[1]));
+}
+template <int NK, bool MULTI>
+__global__ __launch_bounds__(64 * FIC_Q_WPG, NK == 4 ? FIC_Q_WAVES_B8 : 1) void k_sweep_q16(QArgs A)
+{
+    constexpr int CTW = fic_q_ctw(NK), CT = FIC_Q_WPG * CTW, CU = 2 * CTW, KS = NK / 2;
+    __shared__ uint32_t sQ[FIC_Q_WPG][FIC_Q_QCAP + 4];         // per wave: domain block | column-in-wave << 24; [QCAP] = fill count
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int combo_, gx_;
+    xcd_decode(blockIdx.x, A.nchunks * A.planes, A.nctg, combo_, gx_);
+    const int plane = combo_ / A.nchunks;
+    const int chunk = combo_ % A.nchunks;
+    const int ctw0 = A.ct_begin + gx_ * CT + wave * CTW;     // first column tile (x32 columns) of this wave
+    const int dt0 = chunk * A.tiles_per_chunk;
+    int dt1 = dt0 + A.tiles_per_chunk;
+    if (dt1 > A.ndtiles_loop) dt1 = A.ndtiles_loop;
+    if (dt0 >= A.ndtiles || ctw0 >= A.ct_end) return;        // (no barrier in this kernel: waves are independent)
+    const unsigned long long clk0 = A.stats ? clock64() : 0ull, tick0 = A.stats ? wall_clock64() : 0ull;
+    int nci = A.ct_end - ctw0;                               // column tiles this wave really owns (wave-uniform)
+    if (nci > CTW) nci = CTW;
+
+    const int c16 = lane & 15, g4 = lane >> 4;
+    const FicRngStat* rst = A.rng_st + (size_t)plane * A.Nr_pad;
+    uint32_t* const thg = A.theta_g + (size_t)plane * A.Nr_pad;
+    uint32_t* const myq = sQ[wave];
+    uint32_t* const myqn = myq + FIC_Q_QCAP;
+    const uint32_t myqn_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t*)myqn;
+    if (lane == 0) *myqn = 0u;
+
+    v4i rb[CTW][NK];                                         // rb[ci][sub * KS + ks]: columns 16 sub + (lane & 15) of column tile ci
+    {
+        const v4i* rp = A.rngQ + ((size_t)plane * A.nct_alloc + ctw0) * NK * 64 + lane;
+#pragma unroll
+        for (int ci = 0; ci < CTW; ci++)
+#pragma unroll
+            for (int m = 0; m < NK; m++) rb[ci][m] = rp[(ci * NK + m) * 64];
+    }
+    float tau[CU], E[CU];
+    uint32_t okbits = 0, raise = 0;
+#pragma unroll
+    for (int cj = 0; cj < CU; cj++) {
+        const int j = ctw0 * 32 + cj * 16 + c16;             // the lane's column of unit cj = its range block
+        const bool ok = j < A.Nr && (cj >> 1) < nci;
+        const int rem = ok ? rst[j].rem : 0;
+        E[cj] = ok ? A.rngE[(size_t)plane * A.Nr_pad + j] : 0.0f;
+        tau[cj] = (ok && rem != 0 && !A.dbg_noflag) ? FIC_Q_TAU_NONE : FIC_Q_TAU_ALL;
+        okbits |= ok ? 1u << cj : 0u;
+        raise |= (ok && rem != 0) ? 1u << cj : 0u;
+    }
+    const v4i* pa = A.poolQ + (size_t)plane * A.ndtiles_alloc * NK * 64 + lane;
+    const uint32_t AS4* pflat = (const uint32_t AS4*)(uintptr_t)(A.dflat + (size_t)plane * A.ndtiles_alloc);
+    const v4f zero = {0, 0, 0, 0};
+    const float lmin = A.lmin;
+    int qn = 0;
+    unsigned st_slow = 0, st_pairs = 0;
+
+    auto flush = [&]() __attribute__((always_inline)) {
+        q_flush<NK, 0>(A, myq, qn, plane, ctw0, lane);
+        qn = 0;
+        if (lane == 0) *myqn = 0u;
+        __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0), as in k_sweep_q
+    };
+    // element e of the lane's unit: accumulator e >> 2, element e & 3 = row 16 (e >> 2) + 4 g + (e & 3)
+    auto val = [&](const v4f& x0, const v4f& x1, int e) __attribute__((always_inline)) { return fabsf(e < 4 ? x0[e] : x1[e - 4]); };
+    // A unit with flagged entries (or a chunk's first tile): exactly slow_tile of k_sweep_q with this kernel's lane layout
+    auto slow_unit = [&](const v4f& x0, const v4f& x1, float mx, int cj, int dt, bool first) __attribute__((always_inline)) {
+        if (!first && __builtin_amdgcn_ballot_w64(mx > 0.0f) == 0 && pflat[dt] != 0u) return;
+        st_slow++;
+        const bool ok = (okbits >> cj) & 1u;
+        const bool mayraise = (raise >> cj) & 1u;
+        const int colw = cj * 16 + c16;                      // column in wave
+        const int jg = ctw0 * 32 + colw;                     // the column's range block (valid when ok)
+        const uint32_t g = (MULTI && mayraise) ? thg[jg] : 0u;
+        const uint32_t ent0 = (uint32_t)(dt * 32 + 4 * g4) | ((uint32_t)colw << 24);     // entry of element 0; element e adds 16 (e >> 2) + (e & 3)
+        if (first) {                                         // (1) out-of-order seed, only from a pair with L >= lmin
+            const float lo = __fsub_rn(q16_share_max(ok ? mx : 0.0f), E[cj]);
+            if (mayraise && lo >= lmin) tau[cj] = fmaxf(tau[cj], __fsub_rn(__fmul_rn(lo, FIC_Q_LEVEL), E[cj]));
+        }
+        const bool cand0 = first && dt == 0 && g4 == 0 && ok;                // candidate 0 = block 0: always evaluated
+        uint32_t hm = 0;
+#pragma unroll
+        for (int e = 7; e >= 0; e--)
+            hm = __builtin_amdgcn_alignbit(hm, __float_as_uint(__fsub_rn(tau[cj], val(x0, x1, e))), 31);
+                                                                             // (8 elements shifted in: bits 0..7)
+        if (!ok) hm = 0;
+        if (cand0) hm |= 1u;
+        const int cnt = __builtin_popcount(hm);
+        if (cnt != 0) {
+            uint32_t w;
+            asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(w) : "v"(myqn_lds), "v"((uint32_t)cnt) : "memory");
+            int e = __builtin_ctz(hm);
+            myq[w] = ent0 + (uint32_t)((e & 3) + 16 * (e >> 2));
+            for (uint32_t h = hm & (hm - 1); h; h &= h - 1) {
+                e = __builtin_ctz(h);
+                myq[++w] = ent0 + (uint32_t)((e & 3) + 16 * (e >> 2));
+            }
+        }
+        const float mp = cnt != 0 ? mx : -1.0f;
+        const float lo2 = q16_share_max((mayraise && mp >= 0.0f) ? __fsub_rn(mp, E[cj]) : -1.0f);   // (2)
+        if (mayraise && lo2 >= 0.0f) {
+            const float lb = __fsub_rn(__fmul_rn(lo2, FIC_Q_LEVEL), E[cj]);
+            tau[cj] = fmaxf(tau[cj], lb);
+            if (MULTI && lo2 >= lmin && g4 == 0) atomicMax(&thg[jg], f32_orderable(lb));
+        }
+        if (MULTI && mayraise && g != 0u) tau[cj] = fmaxf(tau[cj], f32_from_orderable(g));           // (3)
+        const int tot = __builtin_amdgcn_readfirstlane((int)*(volatile __attribute__((address_space(3))) uint32_t*)(__attribute__((address_space(3))) uint32_t*)myqn);
+        st_pairs += (unsigned)(tot - qn);
+        qn = tot;
+        if (qn > FIC_Q_QFLUSH) flush();
+    };
+    // the two accumulators of unit cj against domain fragments at[rt * KS + ks]
+    auto unit_mfma = [&](const v4i (&at)[NK], int cj, v4f& x0, v4f& x1) __attribute__((always_inline)) {
+        x0 = zero;
+        x1 = zero;
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++) x0 = mfma16_f16(at[ks], rb[cj >> 1][(cj & 1) * KS + ks], x0);
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++) x1 = mfma16_f16(at[KS + ks], rb[cj >> 1][(cj & 1) * KS + ks], x1);
+    };
+
+    v4i a0[NK], a1[NK];
+#pragma unroll
+    for (int m = 0; m < NK; m++) a0[m] = pa[((size_t)dt0 * NK + m) * 64];
+#pragma unroll
+    for (int m = 0; m < NK; m++) a1[m] = pa[((size_t)(dt0 + 1) * NK + m) * 64];
+    v4f x0, x1;
+    unit_mfma(a0, 0, x0, x1);
+    auto step = [&](int dt, v4i (&ac)[NK], const v4i (&an)[NK], const bool first) __attribute__((always_inline)) {
+#pragma unroll
+        for (int cj = 0; cj < CU; cj++) {
+            v4f n0, n1;
+            if (cj + 1 < CU) unit_mfma(ac, cj + 1, n0, n1);
+            else unit_mfma(an, 0, n0, n1);
+            if (cj == CU - 2) {
+#pragma unroll
+                for (int m = 0; m < NK; m++) ac[m] = pa[((size_t)(dt + 2) * NK + m) * 64];
+            }
+            const float mx = max8_abs(x0, x1);
+            const bool hit = mx > tau[cj];
+            if (__builtin_expect((__builtin_amdgcn_ballot_w64(hit) != 0) | first, 0)) slow_unit(x0, x1, mx, cj, dt, first);
+            x0 = n0;
+            x1 = n1;
+        }
+    };
+    for (int dt = dt0; dt < dt1; dt += 2) {
+        step(dt, a0, a1, dt == dt0);
+        step(dt + 1, a1, a0, false);
+    }
+    flush();
+    if (A.stats && lane == 0) {
+        atomicAdd(&A.stats[0], (unsigned long long)(dt1 - dt0) * (unsigned)nci);
+        atomicAdd(&A.stats[1], (unsigned long long)st_slow);
+        atomicAdd(&A.stats[2], (unsigned long long)st_pairs);
+        atomicAdd(&A.stats[3], 1ull);
+        if ((blockIdx.x & 15) == 0 && wave == 0) {
+            atomicAdd(&A.stats[4], (unsigned long long)(clock64() - clk0));
+            atomicAdd(&A.stats[5], (unsigned long long)(wall_clock64() - tick0));
+            atomicAdd(&A.stats[6], 1ull);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // host-side launchers
 // ---------------------------------------------------------------------------------------------
 template <int NK, int MODE>
@@ -933,9 +1151,15 @@ static void q_launch_nm(bool multi, dim3 grid, dim3 block, hipStream_t s, const 
     else hipLaunchKernelGGL((k_sweep_q<NK, MODE, false>), grid, block, 0, s, A);
 }
 // NK = n / 16; mode 0 / 1 / 2 as fic_q_mode, 3 = joint RGB.  false: no such kernel
-static bool q_launch(int NK, int mode, bool multi, dim3 grid, dim3 block, hipStream_t s, const QArgs& A)
+static bool q_launch(int NK, int mode, bool multi, dim3 grid, dim3 block, hipStream_t s, const QArgs& A, int shape16 = 0)
 {
-    if (NK == 1 && mode == 0) q_launch_nm<1, 0>(multi, grid, block, s, A);
+    if (shape16 && mode == 0 && NK == 4) {
+        if (multi) hipLaunchKernelGGL((k_sweep_q16<4, true>), grid, block, 0, s, A);
+        else hipLaunchKernelGGL((k_sweep_q16<4, false>), grid, block, 0, s, A);
+    } else if (shape16 && mode == 0 && NK == 16) {
+        if (multi) hipLaunchKernelGGL((k_sweep_q16<16, true>), grid, block, 0, s, A);
+        else hipLaunchKernelGGL((k_sweep_q16<16, false>), grid, block, 0, s, A);
+    } else if (NK == 1 && mode == 0) q_launch_nm<1, 0>(multi, grid, block, s, A);
     else if (NK == 1 && mode == 1) q_launch_nm<1, 1>(multi, grid, block, s, A);
     else if (NK == 1 && mode == 3) q_launch_nm<1, 3>(multi, grid, block, s, A);
     else if (NK == 4 && mode == 0) q_launch_nm<4, 0>(multi, grid, block, s, A);
@@ -953,6 +1177,17 @@ int fic_q_ctw_host(int B) { return fic_q_ctw(B * B / 16); }
 int fic_q_mode(int B, int n_iso) { return n_iso == 1 ? 0 : (B == 4 ? 1 : 2); }
 int fic_q_cols_per_range(int B, int n_iso) { const int m = fic_q_mode(B, n_iso); return m == 0 ? 1 : (m == 1 ? 8 : 4); }
 int fic_q_unroll(int B, int n_iso) { (void)B; (void)n_iso; return FIC_Q_UNROLL; }
+// 1: this 1-isometry sweep runs on v_mfma_f32_16x16x32_f16 (k_sweep_q16; fragments in that lane order).  Measured
+// (profiles/r03h_mfma_16x16x32_vs_32x32x16_1iso_sweep_ab.txt): the chip holds 1.78 GHz under it against 1.55 under 32x32x16 and
+// large pools gain 7.5 % (4096x4096: B = 8 26.1 -> 24.3 ms, B = 16 7.21 -> 6.71 ms); its units are 16 columns wide, so a
+// small pool -- where a fifth of the tiles is flagged -- pays for twice as many flagged units and loses 3-15 % (64 x 512x512,
+// 4 x 2048x2048, one image).  Hence only from 10^5 MFMA K-steps per range column on: B = 8 from ~25 000 domain tiles, B = 16 from ~6 000.
+int fic_q_shape16(const FicGeom& g)
+{
+    const long long ndtiles = (g.Nd + 31) / 32;
+    if (!FIC_Q_SHAPE16 || g.n_iso != 1 || g.B < 8 || g.q_shape == 2) return 0;
+    return (g.q_shape == 1 || ndtiles * (g.n / 16) >= 100000) ? 1 : 0;
+}
 // workgroups of k_sweep_q a CU holds at once (a workgroup puts one wave on each SIMD; VGPR-bound)
 int fic_q_resident(int B) { return (B == 4 ? FIC_Q_WAVES_B4 : (B == 8 ? FIC_Q_WAVES_B8 : 1)) * 4 / FIC_Q_WPG; }
 
@@ -960,9 +1195,10 @@ int fic_launch_q_prep(const FicBuffers& b, void* poolQ, void* dflat, void* rngQ,
                       const FicGeom& g, int ndtiles_alloc, int nct_alloc, int grp0, int ngrp, hipStream_t s)
 {
     const int mode = fic_q_mode(g.B, g.n_iso);
+    const int shape16 = fic_q_shape16(g);
     auto pool = g.B == 4 ? k_pool_q<4> : (g.B == 8 ? k_pool_q<8> : k_pool_q<16>);
     hipLaunchKernelGGL(pool, dim3(ndtiles_alloc, g.planes), dim3(256), 0, s, (const uint8_t*)b.scaled, b.pool_pix,
-                       b.pool_st, b.pool_var, b.pool_s64, (v4i*)poolQ, (uint32_t*)dflat, g, ndtiles_alloc, mode == 2 ? 1 : 0);
+                       b.pool_st, b.pool_var, b.pool_s64, (v4i*)poolQ, (uint32_t*)dflat, g, ndtiles_alloc, mode == 2 ? 1 : 0, shape16);
     FIC_LAUNCH_CHECK();
     // LDS staging of the byte copies when they fit beside the 16.6 KB of raw blocks (not at B = 16 with 8 isometries: 66 KB)
     const size_t stage_bytes = (size_t)64 * fic_q_cols_per_range(g.B, g.n_iso) * (g.n + 8);
@@ -970,10 +1206,10 @@ int fic_launch_q_prep(const FicBuffers& b, void* poolQ, void* dflat, void* rngQ,
     if (g.B == 8 && mode != 1) {                               // the benchmark's shapes: copies by register permutes, 16-byte stores
         auto rk = mode == 0 ? k_range_q8<0> : k_range_q8<2>;
         hipLaunchKernelGGL(rk, dim3(ngrp, g.planes), dim3(256), 0, s, (const uint8_t*)b.gray, b.rng_st, (float*)rngE, b.key,
-                           (uint32_t*)theta_g, (v4i*)rngQ, (uint32_t*)rngC, g, nct_alloc, grp0);
+                           (uint32_t*)theta_g, (v4i*)rngQ, (uint32_t*)rngC, g, nct_alloc, grp0, shape16);
     } else {
         hipLaunchKernelGGL(k_range_q, dim3(ngrp, g.planes), dim3(256), staged ? stage_bytes : 0, s, (const uint8_t*)b.gray, b.rng_st,
-                           (float*)rngE, b.key, (uint32_t*)theta_g, (v4i*)rngQ, (uint32_t*)rngC, g, nct_alloc, grp0, mode, staged);
+                           (float*)rngE, b.key, (uint32_t*)theta_g, (v4i*)rngQ, (uint32_t*)rngC, g, nct_alloc, grp0, mode, staged, shape16);
     }
     FIC_LAUNCH_CHECK();
     return 0;
@@ -1003,7 +1239,7 @@ int fic_launch_sweep_q(const FicBuffers& b, const void* poolQ, const void* dflat
         return (int)hipErrorInvalidValue;
     dim3 grid((unsigned)(nchunks * g.planes) * (unsigned)A.nctg), block(64 * FIC_Q_WPG);
     const int mode = fic_q_mode(g.B, g.n_iso);
-    if (!q_launch(g.B * g.B / 16, mode, nchunks > 1, grid, block, s, A)) return (int)hipErrorInvalidValue;
+    if (!q_launch(g.B * g.B / 16, mode, nchunks > 1, grid, block, s, A, fic_q_shape16(g))) return (int)hipErrorInvalidValue;
     FIC_LAUNCH_CHECK();
     return 0;
 }

@@ -136,6 +136,12 @@ class Encoder:
         d["clock_ghz"] = d["wave_cycles"] / d["wave_ticks"] / 10.0 if d["wave_ticks"] else None
         return d
 
+    def last_kernel(self):
+        """Name of the sweep kernel the last encode launched, as rocprofv3 prints it (without the argument list)."""
+        buf = C.create_string_buffer(96)
+        capi.check(capi.lib().fic_ctx_last_kernel(self._h, buf, 96))
+        return buf.value.decode()
+
     def info(self):
         v = (C.c_int * 10)()
         capi.check(capi.lib().fic_ctx_info(self._h, v))

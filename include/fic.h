@@ -214,6 +214,8 @@ FIC_API int fic_ctx_decode_host(fic_ctx* ctx, uint8_t* gray_out, float* avg_erro
  *                 (with "sweep" = 0 the environment variable FIC_SWEEP=3 selects the matrix-core sweep process-wide
  *                 for full-search launches of >= 5e7 (B = 4/8) / 5e8 (B = 16) (range, domain) pairs; smaller
  *                 launches and windowed search keep the VALU sweep, which is faster there)
+ *   "q_shape"     matrix instruction of the 1-isometry k_sweep_q at B = 8 / 16: 0 by pool size (default: v_mfma_f32_16x16x32_f16
+ *                 from 10^5 K-steps per range column, else 32x32x16), 1 = 16x16x32 (k_sweep_q16), 2 = 32x32x16; same codebooks
  *   "chunks"      domain-pool chunks per range tile for the fast kernel (0 = auto)
  *   "time_sweep"  1: bracket every sweep launch with hipEvents on its stream */
 FIC_API int fic_ctx_set_option(fic_ctx* ctx, const char* name, int value);
@@ -228,6 +230,9 @@ FIC_API int fic_ctx_sweep_time(fic_ctx* ctx, double* total_ms, int* launches, in
 FIC_API int fic_ctx_sweep_stats(fic_ctx* ctx, uint64_t* out8, int reset);
 /* Geometry actually in use: out[0..9] = Rw, Rh, N_r, Dw, Dh, N_d, NR, tiles, chunks, sweep kind. */
 FIC_API int fic_ctx_info(fic_ctx* ctx, int* out10);
+/* Name of the sweep kernel the context's last encode launched (as rocprofv3 prints it, without the argument list), e.g.
+ * "k_sweep_q<4, 2, false>" or "k_sweep_q16<4, true>" -- so that a caller can match its timing with a profile. */
+FIC_API int fic_ctx_last_kernel(fic_ctx* ctx, char* out, int capacity);
 /* Range blocks one wave of sweep `kind` keeps in registers, i.e. how many range blocks share one read of a pool block
  * (the reuse factor between SURVEY 8(d)'s byte model and the physical traffic): k_sweep_q 32 / 128 (B = 8: 8 / 1
  * isometries), 32 / 256 (B = 4), 16 / 64 (B = 16); the VALU sweeps 64 x NR.  0: not defined for that kind. */

@@ -14,16 +14,19 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
-@pytest.fixture(scope="session", autouse=True)
 def _torch_runtime_first():
     """On a GPU box bring torch's bundled HIP runtime up before libfic_hip.so's (see capi._torch_first): tests that hand
-    torch CUDA tensors to the library must not depend on which test ran first."""
+    torch CUDA tensors to the library must not depend on which test ran first.  Done when conftest is imported, i.e. before
+    any test module is collected: some of them ask the library at import time how it was built (capi.has_xcheck())."""
     try:
         import torch
         if torch.cuda.is_available():
             torch.cuda.init()
     except ImportError:
         pass
+
+
+_torch_runtime_first()
 
 
 @pytest.fixture(scope="session")

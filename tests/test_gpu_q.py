@@ -139,3 +139,58 @@ def test_q_records_are_the_packed_results():
     for k in ("idx_local", "iso", "qrows"):
         assert (back[k] == r[k]).all()
     assert same_f32(back["a"], r["a"]) and same_f32(back["b"], r["b"])
+
+
+def _encode_shape(g, B, shape, chunks=0):
+    h, w = g.shape
+    with fic_amd.Encoder(w, h, B, None, 1) as enc:
+        enc.set_option("sweep", 6)
+        enc.set_option("q_shape", shape)
+        if chunks:
+            enc.set_option("chunks", chunks)
+        enc.set_gray(g)
+        enc.encode()
+        return {k: v[0] for k, v in enc.results().items()}, enc.last_kernel()
+
+
+@pytest.mark.parametrize("name,B", [(n, B) for n in sorted(IMAGES) for B in (8, 16) if not (B == 16 and n in ("lena64", "flat64", "U200"))])
+def test_q16_sweep_matches_oracle(oracle, name, B):
+    """k_sweep_q16: the 1-isometry sweep on v_mfma_f32_16x16x32_f16 (the library takes it for large pools only; option
+    "q_shape" = 1 forces it here) -- every image of this file, chunk counts from one to one per domain tile, against the
+    oracle; and the 32x32x16 kernel on the same inputs."""
+    g = IMAGES[name]
+    ref = _ref(oracle, name, B, 1)
+    for chunks in (0, 1, 3, 50, 10000):
+        got, kname = _encode_shape(g, B, 1, chunks)
+        assert kname.startswith(f"k_sweep_q16<{B * B // 16}, "), kname
+        _check(oracle, got, ref)
+    got, kname = _encode_shape(g, B, 2)
+    assert kname.startswith(f"k_sweep_q<{B * B // 16}, 0, "), kname
+    _check(oracle, got, ref)
+
+
+def test_q16_is_chosen_by_pool_size_and_batches_and_shards():
+    """Default choice: small pools keep 32x32x16; a 4096x4096 pool at B = 8 takes k_sweep_q16 (tests/test_gpu_fullsize.py compares
+    that whole codebook with the VALU sweep).  Batched planes and range shards through the forced 16x16x32 kernel."""
+    imgs = np.stack([IMAGES["lena256"], IMAGES["S256"], synth.image_u(256, 256, 77)])
+    with fic_amd.Encoder(256, 256, 8, None, 1, planes=3) as enc:
+        enc.set_gray(imgs)
+        enc.encode()
+        assert enc.last_kernel().startswith("k_sweep_q<4, 0, ")
+        whole = {k: v.copy() for k, v in enc.results().items()}
+        enc.set_option("q_shape", 1)
+        enc.encode()
+        assert enc.last_kernel().startswith("k_sweep_q16<4, ")
+        forced = {k: v.copy() for k, v in enc.results().items()}
+        parts = []
+        for b, c in fic_amd.shard_spans(enc.n_ranges, enc.ranges_per_tile, 3):
+            enc.encode(b, c)
+            parts.append({k: v[:, b:b + c].copy() for k, v in enc.results().items()})
+    for k in ("idx_local", "idx_global", "iso", "qrows"):
+        assert (forced[k] == whole[k]).all() and (np.concatenate([p[k] for p in parts], axis=1) == whole[k]).all()
+    for k in ("a", "b", "err"):
+        assert same_f32(forced[k], whole[k]) and same_f32(np.concatenate([p[k] for p in parts], axis=1), whole[k])
+    with fic_amd.Encoder(4096, 4096, 8, None, 1) as enc:
+        enc.set_gray(np.zeros((4096, 4096), np.uint8))
+        enc.encode()
+        assert enc.last_kernel().startswith("k_sweep_q16<4, ")
