@@ -352,45 +352,55 @@ __device__ void float_sum_segment_maps(const uint32_t* __restrict__ d, int count
         __syncthreads();
     }
 }
-// the walk over the segments; every thread of the workgroup returns the sum
+// the walk over the segments; every thread of the workgroup returns the sum.  The maps come through LDS, 256 segments at a
+// time: read one by one from global memory by the walking thread they cost a dependent load -- a microsecond -- per segment.
+#define FIC_SUM_WALK_SEGS 256
 __device__ float float_sum_walk(float carry, const uint32_t* __restrict__ d, int count, const uint32_t* __restrict__ maps, int* fallbacks)
 {
+    __shared__ uint32_t w_maps[FIC_SUM_WALK_SEGS * FIC_SUM_KMAPS * 2];
     __shared__ float w_sum;
     __shared__ int w_seg;
     const int t = threadIdx.x, nseg = float_sum_segments(count);
     if (t == 0) { w_sum = carry; w_seg = 0; }
     __syncthreads();
-    for (;;) {
-        if (t == 0) {
-            float sum = w_sum;
-            int seg = w_seg;
-            while (seg < nseg) {
-                if (!(sum == sum) || sum >= 16777216.0f * (float)(1u << (FIC_SUM_KMAPS - 1))) { seg = nseg; break; }   // NaN, or too large to move
-                if (sum != truncf(sum) || sum < 0.0f) break;                                  // fractional carry-in: java_float_sum's head
-                int k = 0;
-                if (sum >= 16777216.0f) k = (int)((__float_as_uint(sum) >> 23) & 0xFF) - 127 - 23;
-                if (k >= FIC_SUM_KMAPS) break;
-                const uint32_t m = (uint32_t)(sum * __uint_as_float((uint32_t)(127 - k) << 23));
-                const uint32_t inc = maps[((size_t)seg * FIC_SUM_KMAPS + k) * 2 + (m & 1u)];
-                if (inc >= FIC_SUM_SAT || m + inc >= FIC_SUM_SAT) break;                      // leaves the binade inside this segment
-                sum = (float)(m + inc) * __uint_as_float((uint32_t)(127 + k) << 23);          // exact: m' < 2^24
-                seg++;
+    for (int c0 = 0; c0 < nseg; c0 += FIC_SUM_WALK_SEGS) {              // uniform
+        const int c1 = c0 + FIC_SUM_WALK_SEGS < nseg ? c0 + FIC_SUM_WALK_SEGS : nseg;
+        for (int i = t; i < (c1 - c0) * FIC_SUM_KMAPS * 2; i += FIC_SUM_THREADS) w_maps[i] = maps[(size_t)c0 * FIC_SUM_KMAPS * 2 + i];
+        __syncthreads();
+        for (;;) {
+            if (t == 0) {
+                float sum = w_sum;
+                int seg = w_seg;
+                while (seg < c1) {
+                    if (!(sum == sum) || sum >= 16777216.0f * (float)(1u << (FIC_SUM_KMAPS - 1))) { seg = nseg; break; }   // NaN, or too large to move
+                    if (sum != truncf(sum) || sum < 0.0f) break;                              // fractional carry-in: java_float_sum's head
+                    int k = 0;
+                    if (sum >= 16777216.0f) k = (int)((__float_as_uint(sum) >> 23) & 0xFF) - 127 - 23;
+                    if (k >= FIC_SUM_KMAPS) break;
+                    const uint32_t m = (uint32_t)(sum * __uint_as_float((uint32_t)(127 - k) << 23));
+                    const uint32_t inc = w_maps[((seg - c0) * FIC_SUM_KMAPS + k) * 2 + (m & 1u)];
+                    if (inc >= FIC_SUM_SAT || m + inc >= FIC_SUM_SAT) break;                  // leaves the binade inside this segment
+                    sum = (float)(m + inc) * __uint_as_float((uint32_t)(127 + k) << 23);      // exact: m' < 2^24
+                    seg++;
+                }
+                w_sum = sum;
+                w_seg = seg;
             }
-            w_sum = sum;
-            w_seg = seg;
+            __syncthreads();
+            const int seg = w_seg;
+            if (seg >= c1) break;                                       // this chunk of segments is done (or everything is)
+            const int len = count - seg * FIC_SUM_SEG < FIC_SUM_SEG ? count - seg * FIC_SUM_SEG : FIC_SUM_SEG;
+            const float s2 = java_float_sum(w_sum, d + (size_t)seg * FIC_SUM_SEG, len);
+            __syncthreads();
+            if (t == 0) {
+                w_sum = s2;
+                w_seg = seg + 1;
+                if (fallbacks) *fallbacks += 1;
+            }
+            __syncthreads();
         }
-        __syncthreads();
-        const int seg = w_seg;
-        if (seg >= nseg) break;
-        const int len = count - seg * FIC_SUM_SEG < FIC_SUM_SEG ? count - seg * FIC_SUM_SEG : FIC_SUM_SEG;
-        const float s2 = java_float_sum(w_sum, d + (size_t)seg * FIC_SUM_SEG, len);
-        __syncthreads();
-        if (t == 0) {
-            w_sum = s2;
-            w_seg = seg + 1;
-            if (fallbacks) *fallbacks += 1;
-        }
-        __syncthreads();
+        if (w_seg >= nseg) break;
+        __syncthreads();                                                // everyone has read w_seg before the maps are replaced
     }
     return w_sum;
 }
