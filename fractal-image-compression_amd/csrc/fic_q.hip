@@ -44,6 +44,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <math.h>
+#include <stdlib.h>
 #include <type_traits>
 #include "fic_device.h"
 #include "fic_launch.h"
@@ -1185,8 +1186,13 @@ int fic_q_unroll(int B, int n_iso) { (void)B; (void)n_iso; return FIC_Q_UNROLL; 
 int fic_q_shape16(const FicGeom& g)
 {
     const long long ndtiles = (g.Nd + 31) / 32;
-    if (!FIC_Q_SHAPE16 || g.n_iso != 1 || g.B < 8 || g.q_shape == 2) return 0;
-    return (g.q_shape == 1 || ndtiles * (g.n / 16) >= 100000) ? 1 : 0;
+    int want = g.q_shape;                                    // option "q_shape"; FIC_Q_SHAPE=1|2 does the same process-wide (profiling runs)
+    if (want == 0) {
+        const char* env = getenv("FIC_Q_SHAPE");
+        if (env && (env[0] == '1' || env[0] == '2') && env[1] == '\0') want = env[0] - '0';
+    }
+    if (!FIC_Q_SHAPE16 || g.n_iso != 1 || g.B < 8 || want == 2) return 0;
+    return (want == 1 || ndtiles * (g.n / 16) >= 100000) ? 1 : 0;
 }
 // workgroups of k_sweep_q a CU holds at once (a workgroup puts one wave on each SIMD; VGPR-bound)
 int fic_q_resident(int B) { return (B == 4 ? FIC_Q_WAVES_B4 : (B == 8 ? FIC_Q_WAVES_B8 : 1)) * 4 / FIC_Q_WPG; }

@@ -230,7 +230,7 @@ def encode_rgb_per_channel(rgb, B, wK=None, n_iso=1, device=0, sweep=0):
     return {k: v.reshape((n, 3) + v.shape[1:]) for k, v in r.items()}
 
 
-def encode_gray(gray, B, wK=None, n_iso=1, device=0, sweep=0, chunks=0):
+def encode_gray(gray, B, wK=None, n_iso=1, device=0, sweep=0, chunks=0, q_shape=0):
     """One grey image (uint8 [H,W]) -> result dict with [N_r] arrays (plane axis dropped)."""
     g = np.ascontiguousarray(gray, np.uint8)
     with Encoder(g.shape[1], g.shape[0], B, wK, n_iso, 1, device) as enc:
@@ -238,6 +238,8 @@ def encode_gray(gray, B, wK=None, n_iso=1, device=0, sweep=0, chunks=0):
             enc.set_option("sweep", sweep)
         if chunks:
             enc.set_option("chunks", chunks)
+        if q_shape:
+            enc.set_option("q_shape", q_shape)
         enc.set_gray(g)
         enc.encode()
         r = enc.results()

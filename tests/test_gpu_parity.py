@@ -506,11 +506,16 @@ def test_seeded_fuzz_geometries_windows_sweeps(oracle):
         ref = oracle.encode_gray(oracle.gray_to_argb(g), w, h, B, wK, n_iso)
         sweeps = [1]
         if wK == Dw == Dh:
-            sweeps += [2, 3, 4, 6]                      # VALU, matrix-core (bf16 / i8 by block size), matrix-core i8, k_sweep_q
+            sweeps += [2, 6]                            # VALU, k_sweep_q
+            if capi.has_xcheck():
+                sweeps += [3, 4]                        # round 1's matrix-core sweeps (bf16 / i8 by block size; i8)
             if B == 8 and n_iso == 8:
                 sweeps.append(5)                        # VALU with algebraic isometries (k_sweep_d4)
+            if B >= 8 and n_iso == 1:
+                sweeps.append(16)                       # k_sweep_q16: "sweep" = 6 with the 16x16x32 MFMA shape forced
         for sweep in sweeps:
-            got = fic_amd.encode_gray(g, B, wK, n_iso, sweep=sweep, chunks=int(rng.integers(0, 4)) if sweep >= 2 else 0)
+            got = fic_amd.encode_gray(g, B, wK, n_iso, sweep=6 if sweep == 16 else sweep, chunks=int(rng.integers(0, 4)) if sweep >= 2 else 0,
+                                      q_shape=1 if sweep == 16 else 0)
             try:
                 _assert_same(oracle, got, ref)
             except AssertionError as e:

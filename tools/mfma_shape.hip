@@ -19,14 +19,15 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 __device__ __forceinline__ float max3f(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
 
-template <int SHAPE>
-__global__ __launch_bounds__(256, 2) void k(const v4i* __restrict__ pool, const v4i* __restrict__ rng, int ndt, float tau,
+// CTW: 32-column tiles per wave (registers: 16 CTW VGPRs of range fragments); WAVES: waves per SIMD the register budget is cut for
+template <int SHAPE, int CTW, int WAVES>
+__global__ __launch_bounds__(256, WAVES) void k(const v4i* __restrict__ pool, const v4i* __restrict__ rng, int ndt, float tau,
                                              unsigned long long* __restrict__ clk, float* __restrict__ out)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    v4i rb[16];
+    v4i rb[4 * CTW];
 #pragma unroll
-    for (int i = 0; i < 16; i++) rb[i] = rng[((blockIdx.x * 4 + wave) * 16 + i) * 64 + lane];
+    for (int i = 0; i < 4 * CTW; i++) rb[i] = rng[(((blockIdx.x * 4 + wave) % 2048) * 16 + i) * 64 + lane];
     const v4i* pa = pool + lane;
     const unsigned long long c0 = clock64(), t0 = wall_clock64();
     int hits = 0;
@@ -53,9 +54,9 @@ __global__ __launch_bounds__(256, 2) void k(const v4i* __restrict__ pool, const 
         v16f acc = tile(a0, 0);
         auto step = [&](int dt, v4i (&ac)[4], const v4i (&an)[4]) __attribute__((always_inline)) {
 #pragma unroll
-            for (int ci = 0; ci < 4; ci++) {
-                v16f nacc = ci + 1 < 4 ? tile(ac, ci + 1) : tile(an, 0);
-                if (ci == 2) {
+            for (int ci = 0; ci < CTW; ci++) {
+                v16f nacc = ci + 1 < CTW ? tile(ac, ci + 1) : tile(an, 0);
+                if (ci == CTW - 2) {
 #pragma unroll
                     for (int m = 0; m < 4; m++) ac[m] = pa[(((dt + 2) % ndt) * 4 + m) * 64];
                 }
@@ -85,11 +86,11 @@ __global__ __launch_bounds__(256, 2) void k(const v4i* __restrict__ pool, const 
         unit(a0, 0, x0, x1);
         auto step = [&](int dt, v4i (&ac)[4], const v4i (&an)[4]) __attribute__((always_inline)) {
 #pragma unroll
-            for (int cj = 0; cj < 8; cj++) {
+            for (int cj = 0; cj < 2 * CTW; cj++) {
                 v4f n0, n1;
-                if (cj + 1 < 8) unit(ac, cj + 1, n0, n1);
+                if (cj + 1 < 2 * CTW) unit(ac, cj + 1, n0, n1);
                 else unit(an, 0, n0, n1);
-                if (cj == 6) {
+                if (cj == 2 * CTW - 2) {
 #pragma unroll
                     for (int m = 0; m < 4; m++) ac[m] = pa[(((dt + 2) % ndt) * 4 + m) * 64];
                 }
@@ -121,7 +122,7 @@ static uint64_t sm(uint64_t& z)
 
 int main(int argc, char** argv)
 {
-    const int ndt = 512, nwg = 512, reps = argc > 1 ? atoi(argv[1]) : 40;     // 512 workgroups = 2 per CU: 2 waves per SIMD
+    const int ndt = 512, nwg = 2048, reps = argc > 1 ? atoi(argv[1]) : 40;     // 512 workgroups = 2 per CU: 2 waves per SIMD
     const size_t np = (size_t)ndt * 4 * 64, nr = (size_t)nwg * 4 * 16 * 64;
     _Float16* hp = (_Float16*)malloc(np * 16);
     _Float16* hr = (_Float16*)malloc(nr * 16);
@@ -140,32 +141,35 @@ int main(int argc, char** argv)
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
-    for (int pass = 0; pass < 2; pass++)
-        for (int shape = 0; shape < 2; shape++) {
-            hipMemset(clk, 0, 16);
-            hipDeviceSynchronize();
-            for (int w = 0; w < 3; w++) {
-                if (shape == 0) hipLaunchKernelGGL(k<0>, dim3(nwg), dim3(256), 0, 0, dp, dr, ndt, 1e30f, clk, out);
-                else hipLaunchKernelGGL(k<1>, dim3(nwg), dim3(256), 0, 0, dp, dr, ndt, 1e30f, clk, out);
-            }
-            hipMemset(clk, 0, 16);
-            hipEventRecord(e0, 0);
-            for (int r = 0; r < reps; r++) {
-                if (shape == 0) hipLaunchKernelGGL(k<0>, dim3(nwg), dim3(256), 0, 0, dp, dr, ndt, 1e30f, clk, out);
-                else hipLaunchKernelGGL(k<1>, dim3(nwg), dim3(256), 0, 0, dp, dr, ndt, 1e30f, clk, out);
-            }
-            hipEventRecord(e1, 0);
-            hipEventSynchronize(e1);
-            float ms = 0;
-            hipEventElapsedTime(&ms, e0, e1);
-            unsigned long long c[2];
-            hipMemcpy(c, clk, 16, hipMemcpyDeviceToHost);
-            const double ghz = c[1] ? (double)c[0] / (double)c[1] / 10.0 : 0.0;
-            const double tiles = (double)reps * nwg * 4 * ndt * 4;                 // 32x32 tile-equivalents
-            const double flop = tiles * 32.0 * 32.0 * 64.0 * 2.0;
-            printf("%-10s %2d launches %8.3f ms  %7.1f TFLOP/s  frac %.3f of 2500  clock %.3f GHz  %.1f cycles per 32x32xK64 tile per SIMD (floor 128)\n",
-                   shape == 0 ? "32x32x16" : "16x16x32", reps, ms, flop / (ms * 1e-3) / 1e12, flop / (ms * 1e-3) / 2.5e15, ghz,
-                   ms * 1e-3 * ghz * 1e9 / (tiles / 1024.0));
-        }
+    auto run = [&](const char* name, auto kern, int ctw, int waves) {
+        const int grid = 256 * waves;                        // `waves` workgroups per CU = `waves` waves per SIMD
+        hipMemset(clk, 0, 16);
+        hipDeviceSynchronize();
+        for (int w = 0; w < 3; w++) hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, 0, dp, dr, ndt, 1e30f, clk, out);
+        hipDeviceSynchronize();
+        hipMemset(clk, 0, 16);
+        hipEventRecord(e0, 0);
+        for (int r = 0; r < reps; r++) hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, 0, dp, dr, ndt, 1e30f, clk, out);
+        hipEventRecord(e1, 0);
+        hipEventSynchronize(e1);
+        float ms = 0;
+        hipEventElapsedTime(&ms, e0, e1);
+        unsigned long long c[2];
+        hipMemcpy(c, clk, 16, hipMemcpyDeviceToHost);
+        const double ghz = c[1] ? (double)c[0] / (double)c[1] / 10.0 : 0.0;
+        const double tiles = (double)reps * grid * 4 * ndt * ctw;                 // 32x32 tile-equivalents
+        const double flop = tiles * 32.0 * 32.0 * 64.0 * 2.0;
+        printf("%-10s CTW %d, %d waves/SIMD: %8.3f ms  %7.1f TFLOP/s  frac %.3f of 2500  clock %.3f GHz  %.1f cycles per 32x32xK64 tile per SIMD (floor 128)\n",
+               name, ctw, waves, ms, flop / (ms * 1e-3) / 1e12, flop / (ms * 1e-3) / 2.5e15, ghz, ms * 1e-3 * ghz * 1e9 / (tiles / 1024.0));
+    };
+    for (int pass = 0; pass < 2; pass++) {
+        run("32x32x16", k<0, 4, 2>, 4, 2);
+        run("16x16x32", k<1, 4, 2>, 4, 2);
+        run("16x16x32", k<1, 3, 3>, 3, 3);
+        run("16x16x32", k<1, 2, 3>, 2, 3);
+        run("16x16x32", k<1, 2, 4>, 2, 4);
+        run("32x32x16", k<0, 3, 3>, 3, 3);
+        run("32x32x16", k<0, 2, 4>, 2, 4);
+    }
     return 0;
 }

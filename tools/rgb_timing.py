@@ -88,3 +88,38 @@ for W, B in ((512, 8), (1024, 8), (1024, 4), (2048, 8), (2048, 16), (4096, 8)):
         row["speedup"] = row["valu"]["ms_per_image"] / row["matrix_core"]["ms_per_image"]
     cmp[f"{W}x{W}_B{B}_full"] = row
 print(json.dumps({"rgb_full_search_valu_vs_matrix_core": cmp}, indent=1))
+
+# natural-image check: the prune bound E_r of k_sweep_q<NK, 3> scales with the GLOBAL Amax = max_d ||A_d||, so its
+# efficiency on natural images is a separate question from the U figure.  LenaColored (tests/golden) tiled to 1024x1024 with a
+# per-tile shift, B = 8, full search, beside three U planes of the same size; both sweeps.
+lena = np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "lena_colored_256.npy")).astype(np.int64)
+nat = {}
+for W in (512, 1024):
+    tiles = W // 256
+    big = np.zeros((W, W, 3), np.int64)
+    for ty in range(tiles):
+        for tx in range(tiles):
+            big[256 * ty:256 * ty + 256, 256 * tx:256 * tx + 256] = np.roll(lena, (17 * ty + 5 * tx, 11 * tx + 3 * ty), axis=(0, 1))
+    lena_argb = ((np.int64(255) << 24) | (big[..., 0] << 16) | (big[..., 1] << 8) | big[..., 2]).astype(np.uint32).view(np.int32).reshape(1, -1)
+    r, g, b = (fic_amd.synth.image_u(W, W, 0xC0400 + c).astype(np.int64) for c in range(3))
+    u_argb = ((np.int64(255) << 24) | (r << 16) | (g << 8) | b).astype(np.uint32).view(np.int32).reshape(1, -1)
+    Dw = fic_amd.geometry(W, W, 8)[2]
+    for name, argb in (("LenaColored_tiled", lena_argb), ("U", u_argb)):
+        t = torch.from_numpy(argb).cuda()
+        row = {}
+        for sweep in (1, 2):
+            with capi.RgbEncoder(W, W, 8, Dw, 1) as enc:
+                enc.set_option("sweep", sweep)
+                enc.set_argb(t)
+                s = torch.cuda.current_stream()
+                enc.encode(False, s)
+                enc.sync()
+                reps = 5
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    enc.encode(False, s)
+                enc.sync()
+                row["valu" if sweep == 1 else "matrix_core"] = {"ms_per_image": (time.perf_counter() - t0) / reps * 1e3}
+        row["speedup"] = row["valu"]["ms_per_image"] / row["matrix_core"]["ms_per_image"]
+        nat[f"{W}x{W}_B8_full_{name}"] = row
+print(json.dumps({"rgb_full_search_natural_vs_U": nat}, indent=1))
