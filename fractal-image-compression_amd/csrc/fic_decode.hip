@@ -258,6 +258,22 @@ __device__ float java_float_sum(float carry, const uint32_t* __restrict__ d, int
 // maps: u32 [segments][FIC_SUM_KMAPS][2].
 // ---------------------------------------------------------------------------------------------
 __host__ __device__ inline int float_sum_segments(int count) { return (count + FIC_SUM_SEG - 1) / FIC_SUM_SEG; }
+// Scratch of one sum behind the values: segment maps u32 [segments][KMAPS][2], the segments' exact totals u64 [segments], and the
+// maps of the 16 sub-segments (one wave's 4096 values each) of every segment u32 [segments][KMAPS][16][2]
+#define FIC_SUM_SUBS (FIC_SUM_THREADS / 64)
+#define FIC_SUM_SUB (64 * FIC_SUM_RUN)
+__host__ __device__ inline size_t float_sum_scratch_words(int count)
+{
+    return (size_t)float_sum_segments(count) * (FIC_SUM_KMAPS * 2 + 2 + FIC_SUM_KMAPS * FIC_SUM_SUBS * 2);
+}
+__device__ __forceinline__ unsigned long long* float_sum_totals(uint32_t* scratch, int count)
+{
+    return (unsigned long long*)(scratch + (size_t)float_sum_segments(count) * FIC_SUM_KMAPS * 2);
+}
+__device__ __forceinline__ uint32_t* float_sum_submaps(uint32_t* scratch, int count)
+{
+    return scratch + (size_t)float_sum_segments(count) * (FIC_SUM_KMAPS * 2 + 2);
+}
 // binade (ulp exponent) of a non-negative value: 0 below 2^24
 __device__ __forceinline__ int float_sum_binade(double v)
 {
@@ -289,8 +305,10 @@ __device__ void float_sum_segment_total(const uint32_t* __restrict__ d, int coun
 // every add rounds to nearest, relative error <= 2^-24 either way -- so with the exact totals of the segments before this
 // one (segtot) the sum enters the segment no lower than binade(lo / f) and leaves it no higher than binade(f hi).
 __device__ void float_sum_segment_maps(const uint32_t* __restrict__ d, int count, int seg, float carry, float f,
-                                       const unsigned long long* __restrict__ segtot, uint32_t* __restrict__ maps)
+                                       const unsigned long long* __restrict__ segtot, uint32_t* __restrict__ maps,
+                                       uint32_t* __restrict__ submaps)
 {
+    uint32_t* const sub = submaps + (size_t)seg * FIC_SUM_KMAPS * FIC_SUM_SUBS * 2;        // [k][wave][2]
     __shared__ uint32_t w0[FIC_SUM_THREADS / 64], w1[FIC_SUM_THREADS / 64];
     __shared__ unsigned long long pre[FIC_SUM_THREADS / 64];
     __shared__ int s_klo, s_khi;
@@ -315,11 +333,17 @@ __device__ void float_sum_segment_maps(const uint32_t* __restrict__ d, int count
         __syncthreads();
     }
     const int klo = s_klo, khi = s_khi;
-    for (int k = t; k < FIC_SUM_KMAPS; k += FIC_SUM_THREADS)
+    for (int i = t; i < FIC_SUM_KMAPS * FIC_SUM_SUBS; i += FIC_SUM_THREADS) {
+        const int k = i / FIC_SUM_SUBS;
         if (k < klo || k > khi) {
-            maps[((size_t)seg * FIC_SUM_KMAPS + k) * 2 + 0] = FIC_SUM_SAT;
-            maps[((size_t)seg * FIC_SUM_KMAPS + k) * 2 + 1] = FIC_SUM_SAT;
+            sub[2 * i] = FIC_SUM_SAT;
+            sub[2 * i + 1] = FIC_SUM_SAT;
+            if ((i % FIC_SUM_SUBS) == 0) {
+                maps[((size_t)seg * FIC_SUM_KMAPS + k) * 2 + 0] = FIC_SUM_SAT;
+                maps[((size_t)seg * FIC_SUM_KMAPS + k) * 2 + 1] = FIC_SUM_SAT;
+            }
         }
+    }
     if (klo > khi) return;
     const int i0 = seg * FIC_SUM_SEG + t * FIC_SUM_RUN;
     uint4 v4[FIC_SUM_RUN / 4];
@@ -341,7 +365,12 @@ __device__ void float_sum_segment_maps(const uint32_t* __restrict__ d, int count
             const uint32_t r0 = __shfl_down(a0, stride, 64), r1 = __shfl_down(a1, stride, 64);
             if ((lane & (2 * stride - 1)) == 0) map_compose(a0, a1, r0, r1);
         }
-        if (lane == 0) { w0[wave] = a0; w1[wave] = a1; }
+        if (lane == 0) {
+            w0[wave] = a0;
+            w1[wave] = a1;
+            sub[(k * FIC_SUM_SUBS + wave) * 2 + 0] = a0;       // the map of this wave's 4096 values: the walk's second level
+            sub[(k * FIC_SUM_SUBS + wave) * 2 + 1] = a1;
+        }
         __syncthreads();
         if (t == 0) {
             uint32_t l0 = w0[0], l1 = w1[0];
@@ -352,15 +381,31 @@ __device__ void float_sum_segment_maps(const uint32_t* __restrict__ d, int count
         __syncthreads();
     }
 }
-// the walk over the segments; every thread of the workgroup returns the sum.  The maps come through LDS, 256 segments at a
-// time: read one by one from global memory by the walking thread they cost a dependent load -- a microsecond -- per segment.
+// The walk over the segments; every thread of the workgroup returns the sum.  The maps come through LDS, 256 segments at a
+// time (read one by one from global memory by the walking thread they cost a dependent load -- a microsecond -- per segment).
+// A segment in which the sum leaves its binade (or still has a fractional part) is walked again at its second level, the 16
+// sub-segments of 4096 values, and only the sub-segment where it happens takes java_float_sum.
 #define FIC_SUM_WALK_SEGS 256
-__device__ float float_sum_walk(float carry, const uint32_t* __restrict__ d, int count, const uint32_t* __restrict__ maps, int* fallbacks)
+__device__ float float_sum_walk(float carry, const uint32_t* __restrict__ d, int count, const uint32_t* __restrict__ maps,
+                                const uint32_t* __restrict__ submaps, int* fallbacks)
 {
     __shared__ uint32_t w_maps[FIC_SUM_WALK_SEGS * FIC_SUM_KMAPS * 2];
+    __shared__ uint32_t w_sub[FIC_SUM_KMAPS * FIC_SUM_SUBS * 2];
     __shared__ float w_sum;
-    __shared__ int w_seg;
+    __shared__ int w_seg, w_part;
     const int t = threadIdx.x, nseg = float_sum_segments(count);
+    // one step: the map `mp` (increments for an even / odd m) applied to the integer-valued sum; false: not applicable here
+    auto apply = [](float& sum, const uint32_t* mp, int stride_k) {
+        if (!(sum == sum) || sum != truncf(sum) || sum < 0.0f) return false;
+        int k = 0;
+        if (sum >= 16777216.0f) k = (int)((__float_as_uint(sum) >> 23) & 0xFF) - 127 - 23;
+        if (k >= FIC_SUM_KMAPS) return true;                                       // too large to move: unchanged
+        const uint32_t m = (uint32_t)(sum * __uint_as_float((uint32_t)(127 - k) << 23));
+        const uint32_t inc = mp[(size_t)k * stride_k + (m & 1u)];
+        if (inc >= FIC_SUM_SAT || m + inc >= FIC_SUM_SAT) return false;            // leaves the binade inside
+        sum = (float)(m + inc) * __uint_as_float((uint32_t)(127 + k) << 23);       // exact: m' < 2^24
+        return true;
+    };
     if (t == 0) { w_sum = carry; w_seg = 0; }
     __syncthreads();
     for (int c0 = 0; c0 < nseg; c0 += FIC_SUM_WALK_SEGS) {              // uniform
@@ -372,31 +417,44 @@ __device__ float float_sum_walk(float carry, const uint32_t* __restrict__ d, int
                 float sum = w_sum;
                 int seg = w_seg;
                 while (seg < c1) {
-                    if (!(sum == sum) || sum >= 16777216.0f * (float)(1u << (FIC_SUM_KMAPS - 1))) { seg = nseg; break; }   // NaN, or too large to move
-                    if (sum != truncf(sum) || sum < 0.0f) break;                              // fractional carry-in: java_float_sum's head
-                    int k = 0;
-                    if (sum >= 16777216.0f) k = (int)((__float_as_uint(sum) >> 23) & 0xFF) - 127 - 23;
-                    if (k >= FIC_SUM_KMAPS) break;
-                    const uint32_t m = (uint32_t)(sum * __uint_as_float((uint32_t)(127 - k) << 23));
-                    const uint32_t inc = w_maps[((seg - c0) * FIC_SUM_KMAPS + k) * 2 + (m & 1u)];
-                    if (inc >= FIC_SUM_SAT || m + inc >= FIC_SUM_SAT) break;                  // leaves the binade inside this segment
-                    sum = (float)(m + inc) * __uint_as_float((uint32_t)(127 + k) << 23);      // exact: m' < 2^24
+                    if (!(sum == sum)) { seg = nseg; break; }                     // NaN stays NaN
+                    if (!apply(sum, w_maps + (size_t)(seg - c0) * FIC_SUM_KMAPS * 2, 2)) break;
                     seg++;
                 }
                 w_sum = sum;
                 w_seg = seg;
+                w_part = 0;
             }
             __syncthreads();
             const int seg = w_seg;
             if (seg >= c1) break;                                       // this chunk of segments is done (or everything is)
-            const int len = count - seg * FIC_SUM_SEG < FIC_SUM_SEG ? count - seg * FIC_SUM_SEG : FIC_SUM_SEG;
-            const float s2 = java_float_sum(w_sum, d + (size_t)seg * FIC_SUM_SEG, len);
+            // second level: the 16 sub-segments of segment `seg`
+            for (int i = t; i < FIC_SUM_KMAPS * FIC_SUM_SUBS * 2; i += FIC_SUM_THREADS)
+                w_sub[i] = submaps[(size_t)seg * FIC_SUM_KMAPS * FIC_SUM_SUBS * 2 + i];
             __syncthreads();
-            if (t == 0) {
-                w_sum = s2;
-                w_seg = seg + 1;
-                if (fallbacks) *fallbacks += 1;
+            for (;;) {
+                if (t == 0) {
+                    float sum = w_sum;
+                    int part = w_part;
+                    while (part < FIC_SUM_SUBS && apply(sum, w_sub + part * 2, FIC_SUM_SUBS * 2)) part++;
+                    w_sum = sum;
+                    w_part = part;
+                }
+                __syncthreads();
+                const int part = w_part;
+                if (part >= FIC_SUM_SUBS) break;
+                const long long off = (long long)seg * FIC_SUM_SEG + (long long)part * FIC_SUM_SUB;
+                const int len = count - off < FIC_SUM_SUB ? (int)(count - off) : FIC_SUM_SUB;
+                const float s2 = len > 0 ? java_float_sum(w_sum, d + off, len) : w_sum;
+                __syncthreads();
+                if (t == 0) {
+                    w_sum = s2;
+                    w_part = part + 1;
+                    if (fallbacks && len > 0) *fallbacks += 1;
+                }
+                __syncthreads();
             }
+            if (t == 0) w_seg = seg + 1;
             __syncthreads();
         }
         if (w_seg >= nseg) break;
@@ -410,12 +468,6 @@ __device__ float float_sum_walk(float carry, const uint32_t* __restrict__ d, int
 __device__ __forceinline__ bool decode_sum_is_exact(float carry, unsigned long long ssd)
 {
     return carry == truncf(carry) && carry >= 0.0f && (double)carry + (double)ssd < 16777216.0;
-}
-// scratch of one plane behind the squares: maps u32 [segments][KMAPS][2], then the segments' exact totals u64 [segments]
-__host__ __device__ inline size_t float_sum_scratch_words(int count) { return (size_t)float_sum_segments(count) * (FIC_SUM_KMAPS * 2 + 2); }
-__device__ __forceinline__ unsigned long long* float_sum_totals(uint32_t* scratch, int count)
-{
-    return (unsigned long long*)(scratch + (size_t)float_sum_segments(count) * FIC_SUM_KMAPS * 2);
 }
 __global__ __launch_bounds__(256) void k_decode_segtot(const FicDecodeState* __restrict__ state, const uint32_t* __restrict__ sqbuf,
                                                        uint32_t* __restrict__ scratch, int counter, int wh)
@@ -434,7 +486,7 @@ __global__ __launch_bounds__(FIC_SUM_THREADS) void k_decode_maps(const FicDecode
     const float carry = st->avg;
     if (decode_sum_is_exact(carry, st->ssd[counter])) return;
     uint32_t* sc = scratch + plane * float_sum_scratch_words(wh);
-    float_sum_segment_maps(sqbuf + (size_t)plane * wh, wh, seg, carry, f, float_sum_totals(sc, wh), sc);
+    float_sum_segment_maps(sqbuf + (size_t)plane * wh, wh, seg, carry, f, float_sum_totals(sc, wh), sc, float_sum_submaps(sc, wh));
 }
 __global__ __launch_bounds__(FIC_SUM_THREADS) void k_decode_step(FicDecodeState* __restrict__ state,
                                                                 const uint32_t* __restrict__ sqbuf, const uint32_t* __restrict__ maps,
@@ -448,7 +500,10 @@ __global__ __launch_bounds__(FIC_SUM_THREADS) void k_decode_step(FicDecodeState*
     const bool exact = decode_sum_is_exact(carry, ssd);
     float avg;
     if (exact) avg = __fadd_rn(carry, (float)ssd);             // every partial sum is an exact float: order is irrelevant
-    else avg = float_sum_walk(carry, sqbuf + (size_t)plane * wh, wh, maps + plane * float_sum_scratch_words(wh), nullptr);
+    else {
+        const uint32_t* sc = maps + plane * float_sum_scratch_words(wh);
+        avg = float_sum_walk(carry, sqbuf + (size_t)plane * wh, wh, sc, float_sum_submaps(const_cast<uint32_t*>(sc), wh), nullptr);
+    }
     if (threadIdx.x != 0) return;
     if (!exact) st->seq_sums += 1;
     avg = __fdiv_rn(avg, (float)wh);                           // FC:413
@@ -468,7 +523,7 @@ __global__ __launch_bounds__(256) void k_float_sum_probe_tot(const uint32_t* __r
 __global__ __launch_bounds__(FIC_SUM_THREADS) void k_float_sum_probe_maps(float carry, const uint32_t* __restrict__ vals, int count,
                                                                          uint32_t* __restrict__ scratch, float f)
 {
-    float_sum_segment_maps(vals, count, blockIdx.x, carry, f, float_sum_totals(scratch, count), scratch);
+    float_sum_segment_maps(vals, count, blockIdx.x, carry, f, float_sum_totals(scratch, count), scratch, float_sum_submaps(scratch, count));
 }
 __global__ __launch_bounds__(FIC_SUM_THREADS) void k_float_sum_probe(float carry, const uint32_t* __restrict__ vals, int count,
                                                                     const uint32_t* __restrict__ scratch, float* __restrict__ out)
@@ -476,7 +531,7 @@ __global__ __launch_bounds__(FIC_SUM_THREADS) void k_float_sum_probe(float carry
     __shared__ int fb;
     if (threadIdx.x == 0) fb = 0;
     __syncthreads();
-    const float r = float_sum_walk(carry, vals, count, scratch, &fb);
+    const float r = float_sum_walk(carry, vals, count, scratch, float_sum_submaps(const_cast<uint32_t*>(scratch), count), &fb);
     if (threadIdx.x == 0) { out[0] = r; out[1] = (float)fb; }
 }
 // (1 + 2^-24)^count, rounded up: how far the float sum of `count` addends can drift from the exact total, as a factor

@@ -157,7 +157,8 @@ def test_multi_workgroup_float_accumulation(case):
     assert np.float32(out.value).view(np.uint32) == np.float32(want).view(np.uint32), (out.value, want)
     nseg = (vals.size + 65535) // 65536
     fb = capi.lib().fic_debug_float_sum_fallbacks()
-    assert fb <= min(nseg, 24), f"{fb} of {nseg} segments took the sequential-order path"
+    # only the 4096-value sub-segments in which the sum changes binade take the sequential-order path: at most ~20 of them
+    assert fb <= 24, f"{fb} sub-segments (of {16 * nseg}) took the sequential-order path"
     if case == "image16M":
         assert nseg == 256 and 1 <= fb <= 24
 
