@@ -394,7 +394,7 @@ int q_sweep(fic_ctx* c, int tile0, int tile1, hipStream_t s, int* nchunks_out)
         // Two reasons to split the pool into chunks, each with its own price (a chunk starts with theta unset: until its
         // first good candidate has been evaluated every pair of every tile is queued -- tens of tiles' worth of work):
         //  fill:    fewer workgroups than the chip holds at once (`resident`): split until two rounds of them exist, but
-        //           keep >= 32 (8 isometries) / 14 (1 isometry) tiles per chunk;
+        //           keep >= 30 (8 isometries) / 14 (1 isometry) tiles per chunk;
         //  balance: the kernel ends with its slowest wave, and one round of equally long waves leaves ~25 % of the
         //           wave-cycles idle (profiles/r02w_chunk_count_sweep.txt): aim for 8 rounds, but only with chunks long
         //           enough (>= 1024 tiles) that the start-up is noise.
@@ -402,10 +402,10 @@ int q_sweep(fic_ctx* c, int tile0, int tile1, hipStream_t s, int* nchunks_out)
         const long long resident = 256LL * fic_q_resident(g.B);
         auto ceil_div = [](long long a, long long b) { return (a + b - 1) / b; };
         // (one image, profiles/r03n_single_image_chunk_count_sweep.json: a chunk restarts theta, and what that costs against
-        //  the parallelism it buys depends on the columns per range block -- with 8 isometries chunks below ~32 domain tiles
+        //  the parallelism it buys depends on the columns per range block -- with 8 isometries chunks below ~30 domain tiles
         //  lose (512x512: 0.086 ms per encode at 16 chunks, 0.092-0.094 at 28), with 1 isometry 14-tile chunks still gain
         //  (0.060 at 35 chunks, 0.061 at 28, 0.076 at 16))
-        const long long min_tiles = g.n_iso == 8 ? 32 : 14;
+        const long long min_tiles = g.n_iso == 8 ? 30 : 14;
         long long fill = base_wg < resident ? ceil_div(2 * resident, base_wg) : 1;
         if (fill > q.ndtiles / min_tiles) fill = q.ndtiles / min_tiles;
         long long bal = ceil_div(8 * resident, base_wg);

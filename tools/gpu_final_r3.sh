@@ -2,6 +2,7 @@
 # Round-3 evidence sessions (gpurun allows 20 minutes per call, hence three parts):
 #   tools/gpu_final_r3.sh A <tag>   full parity suite, default bench line, smoke, sweep matrix, one-shot / RGB / decoder timings, rehearsals
 #   tools/gpu_final_r3.sh C <tag>   RGB timings, the 4-rank rehearsal of the default bench (gloo, one GPU), fuzz soak of every sweep kernel
+#   tools/gpu_final_r3.sh D <tag>   after a late change: bench line + single-image kernel stats + traffic stamp only
 #   tools/gpu_final_r3.sh B <tag>   rocprofv3 kernel stats + SQ / TCC counters of the default bench command, of the 1-isometry 4096x4096
 #                                   sweep under both MFMA shapes, of the single image and the decoder; FETCH / WRITE traffic -> traffic.json
 set -o pipefail
@@ -23,6 +24,14 @@ if [ "$PART" = A ]; then
   timeout -k 10 300 python bench.py --inproc --gpus 1 --workload cfg4 --size 2048 --steps 3 --warmup 1 > $O/${TAG}_inproc1.json 2>> $O/${TAG}_inproc.err || { tail $O/${TAG}_inproc.err; exit 1; }
   FIC_BENCH_BACKEND=gloo timeout -k 10 400 python bench.py --gpus 2 --steps 5 --extra-size 2048 > $O/${TAG}_bench_gloo2.json 2> $O/${TAG}_bench_gloo2.err || { tail -20 $O/${TAG}_bench_gloo2.err; exit 1; }
   echo "part A ok"
+  exit 0
+fi
+if [ "$PART" = D ]; then       # after a late change: the bench line, the single image, the traffic stamp of the final csrc/
+  timeout -k 10 400 python bench.py > $O/${TAG}_bench_default.json 2> $O/${TAG}_bench_default.err || { tail -20 $O/${TAG}_bench_default.err; exit 1; }
+  export TMPDIR=/tmp; cd /tmp
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_prof_single8 -- python3 $R/tools/single_image_trace.py 8 > $O/${TAG}_single8_under_rocprof.json 2> $O/${TAG}_prof_single8.err || exit 1
+  cp "$(find $O/${TAG}_prof_single8 -name '*kernel_stats.csv' | head -1)" $O/${TAG}_single8_kernel_stats.csv && rm -rf $O/${TAG}_prof_single8
+  cd $R && bash tools/gpu_traffic.sh ${TAG} --no-verify
   exit 0
 fi
 if [ "$PART" = C ]; then
