@@ -630,7 +630,13 @@ int fic_ctx_encode(fic_ctx* c, int range_begin, int range_count, void* hip_strea
     int nchunks = 1;
     int rc = FIC_OK;
     // pool build (createCodebuch FC:119) + range prep
-    if (fic_launch_scale(c->b.gray, c->b.scaled, g, s)) return fail(FIC_E_HIP, "k_scale launch failed");
+    // (a small launch of the default sweep builds the scaled image inside its one fused prep kernel: fic_q.hip, k_prep_q8)
+    bool fused_prep = false;
+    if (kind == 6) {
+        const QShape q = q_shape(g);
+        fused_prep = fic_q_prep_fused(g, q.ndtiles_alloc, tile1 * (64 * g.NR) / 64 - tile0 * (64 * g.NR) / 64) != 0;
+    }
+    if (!fused_prep && fic_launch_scale(c->b.gray, c->b.scaled, g, s)) return fail(FIC_E_HIP, "k_scale launch failed");
     if (kind == 6) {
         // fused: k_pool_q = pool + statistics + A fragments, k_range_q = range statistics + key reset + copies + B fragments
         rc = q_prep(c, tile0, tile1, s);

@@ -115,11 +115,15 @@ __device__ __forceinline__ int f16_pair(float lo, float hi)
 //   poolQ[plane][dtile][m][lane] = 8 f16 = normalised pixels [16m + 8h, +8) of block 32*dtile + (lane&31), h = lane>>5.
 //   dflat[plane][dtile] = 1 (u32) when all 32 blocks are flat or beyond N_d (their fragments are zero).
 // ---------------------------------------------------------------------------------------------
-template <int B>
-__global__ __launch_bounds__(256) void k_pool_q(const uint8_t* __restrict__ scaled, uint8_t* __restrict__ pool_pix,
-                                                FicDomStat* __restrict__ pool_st, uint32_t* __restrict__ pool_var,
-                                                double* __restrict__ pool_s64, v4i* __restrict__ poolQ,
-                                                uint32_t* __restrict__ dflat, FicGeom g, int ndtiles_alloc, int folded, int shape16)
+// FUSE: the scaled image is not read but made on the way (scaleImage FC:970-1007, the body of k_scale: 2:1 box average of the
+// grey image, 4th tap 128 when x + 1 >= HEIGHT, FC:993) -- small launches only, where k_scale is nothing but a launch; `scaled`
+// is still written (every block row its own B pixels: the overlap makes that 16-fold redundant, which only a small launch can afford).
+template <int B, bool FUSE>
+__device__ __forceinline__ void pool_q_body(int dtile, int plane, const uint8_t* __restrict__ scaled_in, const uint8_t* __restrict__ gray,
+                                            uint8_t* __restrict__ scaled_out, uint8_t* __restrict__ pool_pix,
+                                            FicDomStat* __restrict__ pool_st, uint32_t* __restrict__ pool_var,
+                                            double* __restrict__ pool_s64, v4i* __restrict__ poolQ,
+                                            uint32_t* __restrict__ dflat, const FicGeom& g, int ndtiles_alloc, int folded, int shape16)
 {
     __shared__ __attribute__((aligned(16))) uint8_t pix[32][256 + 16];
     __shared__ int s_sum[32][16], s_sq[32][16];
@@ -127,7 +131,6 @@ __global__ __launch_bounds__(256) void k_pool_q(const uint8_t* __restrict__ scal
     __shared__ int s_mean[32];
     __shared__ int s_nonflat;
     constexpr int n = B * B, NK = n / 16;
-    const int dtile = blockIdx.x, plane = blockIdx.y;
     if (threadIdx.x == 0) s_nonflat = 0;
     // (a) rows of the tile's blocks: thread = (block i, row ry); a row is ONE load of B bytes (the address is only abstand-aligned:
     //     gfx950 global loads take that), byte sums by v_sad_u8, squares by v_dot4
@@ -139,8 +142,24 @@ __global__ __launch_bounds__(256) void k_pool_q(const uint8_t* __restrict__ scal
         for (int q = 0; q < B / 4; q++) w[q] = 0u;
         if (d < g.Nd) {
             const int c = d % g.Dw, r = d / g.Dw;
-            const uint8_t* src = scaled + (size_t)plane * g.Ws * g.Hs + (size_t)(r * g.abstand + ry) * g.Ws + c * g.abstand;
-            __builtin_memcpy(w, src, B);
+            const size_t so = (size_t)plane * g.Ws * g.Hs + (size_t)(r * g.abstand + ry) * g.Ws + c * g.abstand;
+            if constexpr (!FUSE) {
+                __builtin_memcpy(w, scaled_in + so, B);
+            } else {
+                const int ys = r * g.abstand + ry, xs0 = c * g.abstand;
+                const uint8_t* im = gray + (size_t)plane * g.W * g.H + (size_t)(2 * ys) * g.W + 2 * xs0;
+                uint32_t top[B / 2], bot[B / 2];                         // 2B grey pixels of the two source rows
+                __builtin_memcpy(top, im, 2 * B);
+                __builtin_memcpy(bot, im + g.W, 2 * B);
+#pragma unroll
+                for (int x = 0; x < B; x++) {
+                    const uint32_t t2 = top[x >> 1] >> (16 * (x & 1)), b2 = bot[x >> 1] >> (16 * (x & 1));
+                    const int tap4 = (2 * (xs0 + x) + 1 >= g.H) ? 128 : (int)((b2 >> 8) & 0xffu);      // FC:993 compares with the HEIGHT
+                    const int m = (int)(t2 & 0xffu) + (int)((t2 >> 8) & 0xffu) + (int)(b2 & 0xffu) + tap4;
+                    w[x >> 2] |= (uint32_t)(m / 4) << (8 * (x & 3));
+                }
+                __builtin_memcpy(scaled_out + so, w, B);
+            }
         }
         uint32_t sum = 0, sq = 0;
 #pragma unroll
@@ -219,6 +238,15 @@ __global__ __launch_bounds__(256) void k_pool_q(const uint8_t* __restrict__ scal
         poolQ[((size_t)plane * ndtiles_alloc + dtile) * NK * 64 + t] = v;
     }
     if (threadIdx.x == 0) dflat[(size_t)plane * ndtiles_alloc + dtile] = s_nonflat ? 0u : 1u;
+}
+template <int B>
+__global__ __launch_bounds__(256) void k_pool_q(const uint8_t* __restrict__ scaled, uint8_t* __restrict__ pool_pix,
+                                                FicDomStat* __restrict__ pool_st, uint32_t* __restrict__ pool_var,
+                                                double* __restrict__ pool_s64, v4i* __restrict__ poolQ,
+                                                uint32_t* __restrict__ dflat, FicGeom g, int ndtiles_alloc, int folded, int shape16)
+{
+    pool_q_body<B, false>(blockIdx.x, blockIdx.y, scaled, nullptr, nullptr, pool_pix, pool_st, pool_var, pool_s64, poolQ, dflat, g,
+                          ndtiles_alloc, folded, shape16);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -420,17 +448,16 @@ __device__ __forceinline__ void b8_mirror(const uint32_t (&r)[16], uint32_t (&o)
     }
 }
 template <int MODE>
-__global__ __launch_bounds__(256) void k_range_q8(const uint8_t* __restrict__ gray, FicRngStat* __restrict__ rng_st,
-                                                  float* __restrict__ rngE, unsigned long long* __restrict__ key,
-                                                  uint32_t* __restrict__ theta_g, v4i* __restrict__ rngQ,
-                                                  uint32_t* __restrict__ rngC, FicGeom g, int nct_alloc, int grp0, int shape16)
+__device__ __forceinline__ void range_q8_body(int grp, int plane, const uint8_t* __restrict__ gray, FicRngStat* __restrict__ rng_st,
+                                              float* __restrict__ rngE, unsigned long long* __restrict__ key,
+                                              uint32_t* __restrict__ theta_g, v4i* __restrict__ rngQ,
+                                              uint32_t* __restrict__ rngC, const FicGeom& g, int nct_alloc, int shape16)
 {
     constexpr int B = 8, n = 64, DW = 16, NK = 4, CPR = MODE == 0 ? 1 : 4, STR = 80;     // STR: LDS bytes per block / copy (16-byte aligned rows)
     __shared__ __attribute__((aligned(16))) uint8_t blk[64 * STR];
     __shared__ __attribute__((aligned(16))) uint8_t cpy[MODE == 0 ? 16 : 256 * STR];
     __shared__ int s_rM[64];
-    const int plane = blockIdx.y;
-    const int j0 = (grp0 + blockIdx.x) * 64;
+    const int j0 = grp * 64;
     const uint8_t* img = gray + (size_t)plane * g.W * g.H;
     for (int i = threadIdx.x; i < 64 * B; i += 256) {          // one 8-byte row per thread and pass
         const int l = i >> 3, ry = i & 7;
@@ -537,6 +564,33 @@ __global__ __launch_bounds__(256) void k_range_q8(const uint8_t* __restrict__ gr
         for (int u = 0; u < 4; u++) v[u] = real ? f16_pair((float)a[2 * u], (float)a[2 * u + 1]) : 0;
         if (ct0 + ctl < nct_alloc) rngQ[((size_t)plane * nct_alloc + ct0 + ctl) * NK * 64 + (size_t)m * 64 + lane] = v;
     }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void k_range_q8(const uint8_t* __restrict__ gray, FicRngStat* __restrict__ rng_st,
+                                                  float* __restrict__ rngE, unsigned long long* __restrict__ key,
+                                                  uint32_t* __restrict__ theta_g, v4i* __restrict__ rngQ,
+                                                  uint32_t* __restrict__ rngC, FicGeom g, int nct_alloc, int grp0, int shape16)
+{
+    range_q8_body<MODE>(grp0 + blockIdx.x, blockIdx.y, gray, rng_st, rngE, key, theta_g, rngQ, rngC, g, nct_alloc, shape16);
+}
+// k_prep_q8<MODE> : scale + pool build + range prep of a SMALL launch (one 512x512 image: 493 + 64 workgroups) as ONE launch -- the
+// three kernels are 5-8 us each there and all of it is launch ramp (profiles/r03H_single8_kernel_stats.csv).  Workgroups
+// [0, npool) are domain tiles (pool_q_body with the 2:1 average made on the way), the rest are groups of 64 range blocks.
+template <int MODE>
+__global__ __launch_bounds__(256) void k_prep_q8(const uint8_t* __restrict__ gray, uint8_t* __restrict__ scaled, uint8_t* __restrict__ pool_pix,
+                                                 FicDomStat* __restrict__ pool_st, uint32_t* __restrict__ pool_var,
+                                                 double* __restrict__ pool_s64, v4i* __restrict__ poolQ, uint32_t* __restrict__ dflat,
+                                                 FicRngStat* __restrict__ rng_st, float* __restrict__ rngE,
+                                                 unsigned long long* __restrict__ key, uint32_t* __restrict__ theta_g,
+                                                 v4i* __restrict__ rngQ, uint32_t* __restrict__ rngC, FicGeom g, int ndtiles_alloc,
+                                                 int nct_alloc, int grp0, int shape16)
+{
+    if ((int)blockIdx.x < ndtiles_alloc)
+        pool_q_body<8, true>(blockIdx.x, blockIdx.y, nullptr, gray, scaled, pool_pix, pool_st, pool_var, pool_s64, poolQ, dflat, g, ndtiles_alloc,
+                             MODE == 2 ? 1 : 0, shape16);
+    else
+        range_q8_body<MODE>(grp0 + (int)blockIdx.x - ndtiles_alloc, blockIdx.y, gray, rng_st, rngE, key, theta_g, rngQ, rngC, g, nct_alloc, shape16);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1197,11 +1251,24 @@ int fic_q_shape16(const FicGeom& g)
 // workgroups of k_sweep_q a CU holds at once (a workgroup puts one wave on each SIMD; VGPR-bound)
 int fic_q_resident(int B) { return (B == 4 ? FIC_Q_WAVES_B4 : (B == 8 ? FIC_Q_WAVES_B8 : 1)) * 4 / FIC_Q_WPG; }
 
+// 1: the prep of this launch is one fused kernel that makes the scaled image itself (fic_ctx_encode then skips k_scale)
+int fic_q_prep_fused(const FicGeom& g, int ndtiles_alloc, int ngrp)
+{
+    return (g.B == 8 && (long long)g.planes * (ndtiles_alloc + ngrp) <= 1024) ? 1 : 0;
+}
 int fic_launch_q_prep(const FicBuffers& b, void* poolQ, void* dflat, void* rngQ, void* rngC, void* rngE, void* theta_g,
                       const FicGeom& g, int ndtiles_alloc, int nct_alloc, int grp0, int ngrp, hipStream_t s)
 {
     const int mode = fic_q_mode(g.B, g.n_iso);
     const int shape16 = fic_q_shape16(g);
+    if (fic_q_prep_fused(g, ndtiles_alloc, ngrp)) {
+        auto pk = mode == 0 ? k_prep_q8<0> : k_prep_q8<2>;
+        hipLaunchKernelGGL(pk, dim3(ndtiles_alloc + ngrp, g.planes), dim3(256), 0, s, (const uint8_t*)b.gray, b.scaled, b.pool_pix, b.pool_st,
+                           b.pool_var, b.pool_s64, (v4i*)poolQ, (uint32_t*)dflat, b.rng_st, (float*)rngE, b.key, (uint32_t*)theta_g,
+                           (v4i*)rngQ, (uint32_t*)rngC, g, ndtiles_alloc, nct_alloc, grp0, shape16);
+        FIC_LAUNCH_CHECK();
+        return 0;
+    }
     auto pool = g.B == 4 ? k_pool_q<4> : (g.B == 8 ? k_pool_q<8> : k_pool_q<16>);
     hipLaunchKernelGGL(pool, dim3(ndtiles_alloc, g.planes), dim3(256), 0, s, (const uint8_t*)b.scaled, b.pool_pix,
                        b.pool_st, b.pool_var, b.pool_s64, (v4i*)poolQ, (uint32_t*)dflat, g, ndtiles_alloc, mode == 2 ? 1 : 0, shape16);
