@@ -80,7 +80,7 @@ int ctx_free_all(fic_ctx* c)
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
     c->ev.clear();
     if (c->own_stream) { (void)hipStreamDestroy(c->own_stream); c->own_stream = nullptr; }
-    void* ptrs[] = {c->gray_own, c->argb_stage, c->collage, c->decoded, c->dec_state, c->dec_sq, c->mfma_poolB, c->mfma_rngA, c->mfma_sw, c->mfma_rconst, c->q_pool, c->q_flat, c->q_rng, c->q_rngC, c->q_E, c->q_thg, c->q_stats, c->d4_rng, c->d4_pool, c->b.scaled, c->b.pool_pix, c->b.pool_st, c->b.pool_var,
+    void* ptrs[] = {c->gray_own, c->argb_stage, c->collage, c->decoded, c->dec_state, c->dec_sq, c->mfma_poolB, c->mfma_rngA, c->mfma_sw, c->mfma_rconst, c->q_pool, c->q_flat, c->q_rng, c->q_rngC, c->q_E, c->q_thg, c->q_fin, c->q_stats, c->d4_rng, c->d4_pool, c->b.scaled, c->b.pool_pix, c->b.pool_st, c->b.pool_var,
                     c->b.pool_s64, c->b.rng_pix, c->b.rng_st, c->b.key, c->o.idx_local, c->o.idx_global, c->o.iso,
                     c->o.a, c->o.b, c->o.err, c->o.qrows, c->o.records};
     for (void* p : ptrs)
@@ -382,7 +382,7 @@ int q_prep(fic_ctx* c, int tile0, int tile1, hipStream_t s)
         return fail(FIC_E_HIP, "k_pool_q / k_range_q launch failed");
     return FIC_OK;
 }
-int q_sweep(fic_ctx* c, int tile0, int tile1, hipStream_t s, int* nchunks_out)
+int q_sweep(fic_ctx* c, int tile0, int tile1, hipStream_t s, int* nchunks_out, bool fused_fin = false, int r_begin = 0, int r_count = 0)
 {
     const FicGeom& g = c->g;
     const QShape q = q_shape(g);
@@ -417,8 +417,14 @@ int q_sweep(fic_ctx* c, int tile0, int tile1, hipStream_t s, int* nchunks_out)
     int tiles_per_chunk = (q.ndtiles + nchunks - 1) / nchunks;
     tiles_per_chunk = (tiles_per_chunk + q.unroll - 1) / q.unroll * q.unroll;     // whole iterations of the unrolled sweep loop
     nchunks = (q.ndtiles + tiles_per_chunk - 1) / tiles_per_chunk;
+    if (fused_fin && !c->q_fin) {                      // one counter per (plane, column group); the sweep leaves them at zero
+        const size_t nfin = (size_t)g.planes * (q.nct_alloc / q.CT + 1);
+        HIP_TRY(hipMalloc((void**)&c->q_fin, nfin * sizeof(unsigned int)));
+        HIP_TRY(hipMemsetAsync(c->q_fin, 0, nfin * sizeof(unsigned int), s));
+    }
     if (fic_launch_sweep_q(c->b, c->q_pool, c->q_flat, c->q_rng, c->q_rngC, c->q_E, c->q_thg, g, ct_begin, ct_end, q.ndtiles, q.ndtiles_alloc,
-                           q.nct_alloc, tiles_per_chunk, nchunks, s, c->q_stats, c->opt_noflag))
+                           q.nct_alloc, tiles_per_chunk, nchunks, s, c->q_stats, c->opt_noflag, fused_fin ? &c->o : nullptr, c->q_fin,
+                           r_begin, r_count))
         return fail(FIC_E_HIP, "k_sweep_q launch failed");
     *nchunks_out = nchunks;
     return FIC_OK;
@@ -662,7 +668,7 @@ int fic_ctx_encode(fic_ctx* c, int range_begin, int range_count, void* hip_strea
         if (kind == 1) {
             if (fic_launch_sweep_generic(c->b, g, range_begin, range_count, s)) rc = fail(FIC_E_HIP, "k_sweep_generic launch failed");
         } else if (kind == 6) {
-            rc = q_sweep(c, tile0, tile1, s, &nchunks);
+            rc = q_sweep(c, tile0, tile1, s, &nchunks, fused_prep, range_begin, range_count);   // small launches: finalise in the sweep's tail
         } else if (kind == 5) {
             rc = d4_sweep(c, tile0, tile1 - tile0, s, &nchunks);
         } else if (kind >= 3) {
@@ -675,8 +681,10 @@ int fic_ctx_encode(fic_ctx* c, int range_begin, int range_count, void* hip_strea
     if (rc != FIC_OK) return rc;
     c->last_chunks = nchunks;
     c->last_kind = kind;
+    c->last_fused = fused_prep ? 1 : 0;
     // kinds 5 and 6 build no lane-transposed isometry copies: the finaliser recomputes the winner's covariance from the image
-    if (fic_launch_finalize(c->b, c->o, g, range_begin, range_count, s, (kind == 5 || kind == 6) ? 1 : 0)) return fail(FIC_E_HIP, "k_finalize launch failed");
+    if (!fused_prep &&
+        fic_launch_finalize(c->b, c->o, g, range_begin, range_count, s, (kind == 5 || kind == 6) ? 1 : 0)) return fail(FIC_E_HIP, "k_finalize launch failed");
     c->encoded_any = true;
     return FIC_OK;
 }
@@ -829,7 +837,8 @@ int fic_ctx_last_kernel(fic_ctx* c, char* out, int capacity)
         const bool bf16 = kind == 3 && (g.B <= 8 || g.n_iso == 8);
         snprintf(buf, sizeof(buf), "%s%s", bf16 ? "k_sweep_bf16" : "k_sweep_mfma", g.n_iso == 8 ? "" : (bf16 ? "_1" : "1"));
     } else snprintf(buf, sizeof(buf), "(none)");
-    snprintf(out, (size_t)capacity, "%s", buf);
+    // a small launch of the default sweep: one fused prep kernel before it, k_finalize's work in its tail (2 kernels, not 5)
+    snprintf(out, (size_t)capacity, "%s%s", buf, kind == 6 && c->last_fused ? " after k_prep_q8, finalising" : "");
     return FIC_OK;
 }
 

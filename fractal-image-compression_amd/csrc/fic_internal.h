@@ -81,6 +81,7 @@ struct fic_ctx {
     void* q_rngC = nullptr;                  // the sweep columns' isometry copies as bytes (exact evaluation of flagged pairs)
     void* q_E = nullptr;
     void* q_thg = nullptr;
+    unsigned int* q_fin = nullptr;           // fused finalise of small launches: finished workgroups per (plane, column group)
     unsigned long long* q_stats = nullptr;   // "sweep_stats" = 1: device counters of k_sweep_q (fic_ctx_sweep_stats)
     uint32_t* d4_rng = nullptr;      // k_sweep_d4: range / domain slots of the group-Fourier form (n_iso = 8, B = 8 / 16)
     uint32_t* d4_pool = nullptr;
@@ -89,7 +90,7 @@ struct fic_ctx {
     hipStream_t last_stream = nullptr;
     hipStream_t own_stream = nullptr; // non-blocking stream of the multi-device entry (created on demand)
     int opt_sweep = 0, opt_chunks = 0, opt_time = 0, opt_noflag = 0;
-    int last_chunks = 0, last_kind = 0;
+    int last_chunks = 0, last_kind = 0, last_fused = 0;
     std::vector<hipEvent_t> ev;      // pairs start/stop
     double acc_ms = 0.0;
     int acc_n = 0;

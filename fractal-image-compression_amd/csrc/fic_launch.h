@@ -37,6 +37,45 @@ struct FicOutputs {
     int32_t* records;     // [planes][Nr][6] {idx_local, a bits, b bits, iso, (int)(a*100), (int)b}: the unit of the multi-GPU gather
 };
 
+#ifdef __HIPCC__
+#include "fic_devfn.h"
+// The tail of getBestDomainblock (FC:634-642: a = cov / varD, clamp, b = rM - a dM, never fused) + writeData's quantiser (FC:242-244)
+// + the packed 24-byte record, for range j whose winner is (window-local wloc, pool block gi, isometry k); acc = sum copy_k[pos] d[pos].
+// Shared by k_finalize and by the sweep's fused tail (fic_q.hip).
+__device__ __forceinline__ void finalize_store(const FicOutputs& out, const FicGeom& g, int plane, int j, unsigned long long kk, int wloc,
+                                               int gi, int k, uint32_t acc, FicDomStat ds, FicRngStat rs, uint32_t varu)
+{
+    int dM = (int)(ds.sum >> g.lgn);
+    int cov = (int)acc - rs.rM * (int)ds.sum - dM * rs.rem;
+    float var = (float)varu;
+    float a = __fdiv_rn((float)cov, var);              // FC:634  (0/0 -> NaN when a flat block wins)
+    if (a < -1.0f) a = -1.0f;                          // FC:636-639 (NaN passes through)
+    else if (a > 1.0f) a = 1.0f;
+    float b = __fsub_rn((float)rs.rM, __fmul_rn(a, (float)dM));   // FC:641, never fused
+    size_t o = (size_t)plane * g.Nr + j;
+    const int qa = java_f2i(__fmul_rn(a, 100.0f)), qb = java_f2i(b);
+    out.qrows[3 * o + 0] = wloc;                       // (int) imageInfo[row][0]
+    out.qrows[3 * o + 1] = qa;
+    out.qrows[3 * o + 2] = qb;
+    if (a != a) a = __uint_as_float(0x7FC00000u);      // canonical NaN (Java has one NaN value)
+    if (b != b) b = __uint_as_float(0x7FC00000u);
+    out.idx_local[o] = wloc;
+    out.idx_global[o] = gi;
+    out.iso[o] = k;
+    out.a[o] = a;
+    out.b[o] = b;
+    out.err[o] = f32_from_orderable((uint32_t)(kk >> 32));
+    // the same row once more as one 24-byte record: what a rank contributes to the codebook gather
+    int32_t* rec = out.records + 6 * o;
+    rec[0] = wloc;
+    rec[1] = (int32_t)__float_as_uint(a);
+    rec[2] = (int32_t)__float_as_uint(b);
+    rec[3] = k;
+    rec[4] = qa;
+    rec[5] = qb;
+}
+#endif
+
 int fic_launch_argb_to_gray(const int32_t* argb, uint8_t* gray, size_t npix, hipStream_t s);
 int fic_launch_scale(const uint8_t* gray, uint8_t* scaled, const FicGeom& g, hipStream_t s);
 int fic_launch_pool(const uint8_t* scaled, uint8_t* pool_pix, FicDomStat* st, uint32_t* var, double* s64,
@@ -126,7 +165,8 @@ int fic_launch_q_prep(const FicBuffers& b, void* poolQ, void* dflat, void* rngQ,
                       const FicGeom& g, int ndtiles_alloc, int nct_alloc, int grp0, int ngrp, hipStream_t s);
 int fic_launch_sweep_q(const FicBuffers& b, const void* poolQ, const void* dflat, const void* rngQ, const void* rngC, const void* rngE,
                        void* theta_g, const FicGeom& g, int ct_begin, int ct_end, int ndtiles, int ndtiles_alloc,
-                       int nct_alloc, int tiles_per_chunk, int nchunks, hipStream_t s, unsigned long long* stats = nullptr, int dbg_noflag = 0);
+                       int nct_alloc, int tiles_per_chunk, int nchunks, hipStream_t s, unsigned long long* stats = nullptr, int dbg_noflag = 0,
+                       const FicOutputs* fin_out = nullptr, unsigned int* fin_count = nullptr, int r_begin = 0, int r_count = 0);
 int fic_launch_decode_iteration_rgb(int32_t* scaled, int32_t* image, const int32_t* qrows5, FicDecodeState* state,
                                     uint32_t* sqbuf, int counter, const FicGeom& g, hipStream_t s);
 

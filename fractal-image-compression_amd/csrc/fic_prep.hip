@@ -223,33 +223,7 @@ __global__ __launch_bounds__(256) void k_finalize(const uint32_t* __restrict__ p
     } else {
         for (int dw = 0; dw < g.DW; dw++) acc = __builtin_amdgcn_udot4(rp[rng_word_index(g, j, k, dw)], pp[dw], acc, false);
     }
-    int dM = (int)(ds.sum >> g.lgn);
-    int cov = (int)acc - rs.rM * (int)ds.sum - dM * rs.rem;
-    float var = (float)pool_var[(size_t)plane * g.Nd_pad + gi];
-    float a = __fdiv_rn((float)cov, var);              // FC:634  (0/0 -> NaN when a flat block wins)
-    if (a < -1.0f) a = -1.0f;                          // FC:636-639 (NaN passes through)
-    else if (a > 1.0f) a = 1.0f;
-    float b = __fsub_rn((float)rs.rM, __fmul_rn(a, (float)dM));   // FC:641, never fused
-    size_t o = (size_t)plane * g.Nr + j;
-    out.qrows[3 * o + 0] = wloc;                       // (int) imageInfo[row][0]
-    out.qrows[3 * o + 1] = java_f2i(__fmul_rn(a, 100.0f));
-    out.qrows[3 * o + 2] = java_f2i(b);
-    if (a != a) a = __uint_as_float(0x7FC00000u);      // canonical NaN (Java has one NaN value)
-    if (b != b) b = __uint_as_float(0x7FC00000u);
-    out.idx_local[o] = wloc;
-    out.idx_global[o] = gi;
-    out.iso[o] = k;
-    out.a[o] = a;
-    out.b[o] = b;
-    out.err[o] = f32_from_orderable((uint32_t)(kk >> 32));
-    // the same row once more as one 24-byte record: what a rank contributes to the codebook gather
-    int32_t* rec = out.records + 6 * o;
-    rec[0] = wloc;
-    rec[1] = (int32_t)__float_as_uint(a);
-    rec[2] = (int32_t)__float_as_uint(b);
-    rec[3] = k;
-    rec[4] = out.qrows[3 * o + 1];
-    rec[5] = out.qrows[3 * o + 2];
+    finalize_store(out, g, plane, j, kk, wloc, gi, k, acc, ds, rs, pool_var[(size_t)plane * g.Nd_pad + gi]);
 }
 
 // ---------------------------------------------------------------------------------------------

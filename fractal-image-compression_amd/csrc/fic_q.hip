@@ -44,6 +44,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <math.h>
+#include <string.h>
 #include <stdlib.h>
 #include <type_traits>
 #include "fic_device.h"
@@ -629,6 +630,13 @@ struct QArgs {
     int ct_begin, ct_end;            // column tiles (x32 columns) of this shard
     int nctg;                        // column-tile groups (workgroups) in this launch
     int tiles_per_chunk, nchunks, planes;
+    // fused finalise (small launches; fin_count == nullptr: k_finalize runs as its own launch)
+    unsigned int* fin_count;         // [planes][nctg] workgroups of a (plane, column group) that have finished; the last one finalises
+    FicOutputs out;
+    FicGeom geom;
+    const uint8_t* gray;
+    const uint32_t* pool_var;
+    int r_begin, r_end;              // the range blocks this launch encodes
     int dbg_noflag;                  // diagnostic (option "q_noflag"): theta = "never" for every range -- the sweep's floor without any flagged tile (WRONG codebooks)
 };
 
@@ -766,6 +774,59 @@ __device__ __forceinline__ float q_share_max(float v)
     return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
 }
 
+// Fused finalise of a SMALL launch (one 512x512 image: k_finalize is 7 us of launch ramp behind a 58 us sweep).  Every wave
+// calls this when it is done (also waves without work); the last wave of the last workgroup of a (plane, column group) -- all
+// pool chunks of that group have then merged their candidates into `key` -- does what k_finalize does for the group's range
+// blocks: the winner's covariance gathered from the image, fit, clamp, quantise, packed record (finalize_store).
+// Visibility without any cache maintenance (an agent-scope fence = buffer_wbl2 + buffer_inv per wave: the sweep ran 2x longer
+// with one): `key` is touched by nothing but 8-byte device-scope atomics in this kernel -- they execute at the memory side, no
+// L2 holds a line of it (MI355X_MICROARCH.md, "8-B agent atomics both sides") -- so a wave only has to WAIT for its own
+// atomicMins (s_waitcnt vmcnt(0)) before it counts itself done in LDS; the workgroup's last wave then adds to the group's
+// counter, and the wave whose add returns nchunks - 1 reads every key by a returning atomic (umin with ~0).  Everything else it reads was
+// written by the prep kernel.  The counter is left at 0 for the next launch.
+template <int NK, int MODE>
+__device__ __forceinline__ void q_finalize_tail(const QArgs& A, int plane, int gx, int* s_wdone, int lane)
+{
+    if constexpr (MODE == 3) {
+        return;
+    } else {
+        constexpr int CSHIFT = QMode<MODE>::CSHIFT, NISO = QMode<MODE>::NISO;
+        constexpr int B = NK == 1 ? 4 : (NK == 4 ? 8 : 16);
+        constexpr int CT = FIC_Q_WPG * fic_q_ctw(NK);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");             // this wave's atomicMins have been performed
+        int last = 0;
+        if (lane == 0 && atomicAdd(s_wdone, 1) == FIC_Q_WPG - 1) {                // the workgroup's last wave
+            unsigned int* cnt = A.fin_count + (size_t)plane * A.nctg + gx;
+            if (__hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)A.nchunks - 1u) {   // ... of the group's last workgroup
+                last = 1;
+                __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        if (!__builtin_amdgcn_readfirstlane(last)) return;
+        const FicGeom& g = A.geom;
+        const int j0 = ((A.ct_begin + gx * CT) * 32) >> CSHIFT, nj = (CT * 32) >> CSHIFT;
+        for (int jj = lane; jj < nj; jj += 64) {
+            const int j = j0 + jj;
+            if (j < A.r_begin || j >= A.r_end) continue;
+            // (a real read-modify-write, executed where the sweep's atomicMins were: the compiler would turn an idempotent
+            //  __hip_atomic_fetch_min(p, ~0) into an L2-served load)
+            unsigned long long kk;
+            const unsigned long long none = FIC_KEY_NONE;
+            asm volatile("global_atomic_umin_x2 %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)"
+                         : "=&v"(kk) : "v"(A.key + (size_t)plane * A.Nr_pad + j), "v"(none) : "memory");
+            const uint32_t c = (uint32_t)kk;
+            const int wloc = (int)(c / (uint32_t)NISO), k = (int)(c % (uint32_t)NISO);    // full search: window-local == pool index
+            const int gi = wloc;
+            const uint32_t* pp = (const uint32_t*)(A.pool_pix + ((size_t)plane * A.Nd_pad + gi) * A.n);
+            const uint8_t* blk = A.gray + (size_t)plane * g.W * g.H + (size_t)((j / g.Rw) * B) * g.W + (j % g.Rw) * B;
+            uint32_t acc = 0, s2;
+            iso_dot<B, false>(blk, g.W, k, pp, acc, s2);
+            finalize_store(A.out, g, plane, j, kk, wloc, gi, k, acc, A.pool_st[(size_t)plane * A.Nd_pad + gi],
+                           A.rng_st[(size_t)plane * A.Nr_pad + j], A.pool_var[(size_t)plane * A.Nd_pad + gi]);
+        }
+    }
+}
+
 // Launch bounds: the register budget is cut for FIC_Q_WAVES_* waves per SIMD (<= 256 VGPRs at B = 4 / 8), which also makes the
 // compiler emit the MFMAs with VGPR destinations whatever the build flags say (the library is built with -mllvm
 // -amdgpu-mfma-vgpr-form; with accumulators in AGPRs every element the epilogue tests costs a v_accvgpr_read first).
@@ -789,7 +850,15 @@ __global__ __launch_bounds__(64 * FIC_Q_WPG, NK == 4 ? FIC_Q_WAVES_B8 : (NK < 4 
     const int dt0 = chunk * A.tiles_per_chunk;               // tiles_per_chunk is a multiple of the loop's unroll factor;
     int dt1 = dt0 + A.tiles_per_chunk;                       // the last chunk runs into the store's zero tiles (flagged flat)
     if (dt1 > A.ndtiles_loop) dt1 = A.ndtiles_loop;
-    if (dt0 >= A.ndtiles || ctw0 >= A.ct_end) return;        // (no barrier in this kernel: waves are independent)
+    __shared__ int s_wdone;                                  // fused finalise: waves of this workgroup that are done
+    if (A.fin_count) {                                       // (uniform; the only barrier of the kernel, before any wave leaves)
+        if (threadIdx.x == 0) s_wdone = 0;
+        __syncthreads();
+    }
+    if (dt0 >= A.ndtiles || ctw0 >= A.ct_end) {              // (waves are independent: no barrier in the sweep itself)
+        if (A.fin_count) q_finalize_tail<NK, MODE>(A, plane, gx_, &s_wdone, lane);
+        return;
+    }
     const unsigned long long clk0 = A.stats ? clock64() : 0ull, tick0 = A.stats ? wall_clock64() : 0ull;
     int nci = A.ct_end - ctw0;                               // column tiles this wave really owns (wave-uniform)
     if (nci > CTW) nci = CTW;
@@ -1001,6 +1070,7 @@ __global__ __launch_bounds__(64 * FIC_Q_WPG, NK == 4 ? FIC_Q_WAVES_B8 : (NK < 4 
             atomicAdd(&A.stats[6], 1ull);
         }
     }
+    if (A.fin_count) q_finalize_tail<NK, MODE>(A, plane, gx_, &s_wdone, lane);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1050,7 +1120,15 @@ __global__ __launch_bounds__(64 * FIC_Q_WPG, NK == 4 ? FIC_Q_WAVES_B8 : 1) void 
     const int dt0 = chunk * A.tiles_per_chunk;
     int dt1 = dt0 + A.tiles_per_chunk;
     if (dt1 > A.ndtiles_loop) dt1 = A.ndtiles_loop;
-    if (dt0 >= A.ndtiles || ctw0 >= A.ct_end) return;        // (no barrier in this kernel: waves are independent)
+    __shared__ int s_wdone;                                  // fused finalise: waves of this workgroup that are done
+    if (A.fin_count) {                                       // (uniform; the only barrier of the kernel, before any wave leaves)
+        if (threadIdx.x == 0) s_wdone = 0;
+        __syncthreads();
+    }
+    if (dt0 >= A.ndtiles || ctw0 >= A.ct_end) {              // (waves are independent: no barrier in the sweep itself)
+        if (A.fin_count) q_finalize_tail<NK, 0>(A, plane, gx_, &s_wdone, lane);
+        return;
+    }
     const unsigned long long clk0 = A.stats ? clock64() : 0ull, tick0 = A.stats ? wall_clock64() : 0ull;
     int nci = A.ct_end - ctw0;                               // column tiles this wave really owns (wave-uniform)
     if (nci > CTW) nci = CTW;
@@ -1194,6 +1272,7 @@ __global__ __launch_bounds__(64 * FIC_Q_WPG, NK == 4 ? FIC_Q_WAVES_B8 : 1) void 
             atomicAdd(&A.stats[6], 1ull);
         }
     }
+    if (A.fin_count) q_finalize_tail<NK, 0>(A, plane, gx_, &s_wdone, lane);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1290,11 +1369,16 @@ int fic_launch_q_prep(const FicBuffers& b, void* poolQ, void* dflat, void* rngQ,
 
 int fic_launch_sweep_q(const FicBuffers& b, const void* poolQ, const void* dflat, const void* rngQ, const void* rngC, const void* rngE,
                        void* theta_g, const FicGeom& g, int ct_begin, int ct_end, int ndtiles, int ndtiles_alloc,
-                       int nct_alloc, int tiles_per_chunk, int nchunks, hipStream_t s, unsigned long long* stats, int dbg_noflag)
+                       int nct_alloc, int tiles_per_chunk, int nchunks, hipStream_t s, unsigned long long* stats, int dbg_noflag,
+                       const FicOutputs* fin_out, unsigned int* fin_count, int r_begin, int r_count)
 {
     QArgs A;
     A.stats = stats;
     A.dbg_noflag = dbg_noflag;
+    // fused finalise: the sweep's last workgroup per (plane, column group) does k_finalize's work for that group
+    A.fin_count = fin_out ? fin_count : nullptr;
+    if (fin_out) A.out = *fin_out; else memset(&A.out, 0, sizeof(A.out));
+    A.geom = g; A.gray = b.gray; A.pool_var = b.pool_var; A.r_begin = r_begin; A.r_end = r_begin + r_count;
     A.poolQ = (const v4i*)poolQ; A.dflat = (const uint32_t*)dflat; A.pool_pix = b.pool_pix; A.pool_st = b.pool_st;
     A.pool_s64 = b.pool_s64; A.rngQ = (const v4i*)rngQ; A.rngC = (const uint32_t*)rngC; A.rng_st = b.rng_st;
     A.rngE = (const float*)rngE; A.key = b.key; A.theta_g = (uint32_t*)theta_g;
@@ -1442,6 +1526,7 @@ int fic_launch_rgbq(const uint16_t* pool_sum, const FicRgbDomStat* pool_st, cons
     QArgs A;
     A.stats = nullptr;
     A.dbg_noflag = 0;
+    A.fin_count = nullptr; memset(&A.out, 0, sizeof(A.out)); A.geom = g; A.gray = nullptr; A.pool_var = nullptr; A.r_begin = 0; A.r_end = 0;
     A.poolQ = (const v4i*)poolQ; A.dflat = (const uint32_t*)dflat; A.pool_pix = nullptr; A.pool_st = nullptr; A.pool_s64 = nullptr;
     A.rngQ = (const v4i*)rngQ; A.rngC = nullptr; A.rng_st = (const FicRngStat*)qst; A.rngE = (const float*)rngE; A.key = key;
     A.theta_g = (uint32_t*)theta_g;

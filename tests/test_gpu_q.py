@@ -194,3 +194,54 @@ def test_q16_is_chosen_by_pool_size_and_batches_and_shards():
         enc.set_gray(np.zeros((4096, 4096), np.uint8))
         enc.encode()
         assert enc.last_kernel().startswith("k_sweep_q16<4, ")
+
+
+def test_small_launches_run_as_two_kernels(oracle):
+    """A small launch of the default sweep (fic_q_prep_fused: B = 8, at most 1024 prep workgroups) is k_prep_q8 + the sweep, whose
+    last workgroup per (plane, range-column group) finalises that group's range blocks (q_finalize_tail, fic_q.hip) -- no k_scale /
+    k_pool_q / k_range_q8 / k_finalize launches.  Checked: the library says so (last_kernel suffix); results equal the VALU
+    sweep's (whose finaliser is k_finalize) for 8 and 1 isometries, one and many pool chunks, both MFMA shapes, repeated encodes
+    on one context (the group counters must be back at zero), range shards that begin and end inside a column group, and two
+    planes; a 64-plane launch is not small and keeps the separate kernels."""
+    FUSED = " after k_prep_q8, finalising"
+    g = synth.image_u(512, 512, synth.SEEDS["cfg2"])
+    for n_iso in (8, 1):
+        want = fic_amd.encode_gray(g, 8, None, n_iso, sweep=2)
+        with fic_amd.Encoder(512, 512, 8, None, n_iso) as enc:
+            enc.set_gray(g)
+            for chunks, shape in ((0, 0), (0, 0), (1, 0), (7, 0), (500, 0), (0, 1), (3, 1), (0, 0)):
+                if n_iso == 8 and shape:
+                    continue
+                enc.set_option("chunks", chunks)
+                enc.set_option("q_shape", shape)
+                enc.encode()
+                assert enc.last_kernel().endswith(FUSED), enc.last_kernel()
+                got = {k: v[0] for k, v in enc.results().items()}
+                for k in ("idx_local", "idx_global", "iso", "qrows"):
+                    assert (got[k] == want[k]).all(), (n_iso, chunks, shape, k)
+                for k in ("a", "b", "err"):
+                    assert same_f32(got[k], want[k]), (n_iso, chunks, shape, k)
+            enc.set_option("chunks", 0)
+            enc.set_option("q_shape", 0)
+            # shards: spans of whole range tiles, and one ragged span inside a tile
+            tile = enc.ranges_per_tile
+            for b, c in list(fic_amd.shard_spans(enc.n_ranges, tile, 5)) + [(tile + 3, 2 * tile + 11)]:
+                enc.encode(b, c)
+                assert enc.last_kernel().endswith(FUSED)
+                got = {k: v[0, b:b + c] for k, v in enc.results().items()}
+                for k in ("idx_local", "idx_global", "iso", "qrows"):
+                    assert (got[k] == want[k][b:b + c]).all(), (n_iso, b, c, k)
+                for k in ("a", "b", "err"):
+                    assert same_f32(got[k], want[k][b:b + c]), (n_iso, b, c, k)
+    imgs = np.stack([IMAGES["lena256"], IMAGES["S256"]])
+    with fic_amd.Encoder(256, 256, 8, None, 8, planes=2) as enc:
+        enc.set_gray(imgs)
+        enc.encode()
+        assert enc.last_kernel().endswith(FUSED)
+        got = enc.results()
+    for p, name in enumerate(("lena256", "S256")):
+        _check(oracle, {k: v[p] for k, v in got.items()}, _ref(oracle, name, 8, 8))
+    with fic_amd.Encoder(256, 256, 8, None, 8, planes=64) as enc:
+        enc.set_gray(np.stack([IMAGES["lena256"]] * 64))
+        enc.encode()
+        assert enc.last_kernel() == "k_sweep_q<4, 2, false>" or enc.last_kernel() == "k_sweep_q<4, 2, true>", enc.last_kernel()
