@@ -764,6 +764,18 @@ def main():
     if world == 1 and not args.no_alt and plain:
         watchdog.stage = "single_image"
         out["single_image"] = single_image(fic_amd, torch, run.make_image(run.seed), B, n_iso, local_rank, args.sweep)
+        # config 2 names LenaGrey: the same encode on a natural image (the 256x256 fixture enlarged bilinearly), checked against
+        # the VALU-only sweep -- smooth blocks prune differently from iid bytes
+        watchdog.stage = "natural_image"
+        lena = np.load(os.path.join(ROOT, "tests", "golden", "lena_grey_256.npy"))
+        nat = fic_amd.synth.enlarge(lena, wl["W"], wl["H"])
+        ni = single_image(fic_amd, torch, nat, B, n_iso, local_rank, args.sweep, reps=100)
+        ni["workload"] = f"one {wl['W']}x{wl['H']} natural grey image (LenaGrey 256x256 enlarged bilinearly), B={B}, full search, {n_iso} iso"
+        a_ = fic_amd.encode_gray(nat, B, None, n_iso, device=local_rank, sweep=args.sweep)
+        b_ = fic_amd.encode_gray(nat, B, None, n_iso, device=local_rank, sweep=5 if (B == 8 and n_iso == 8) else 2)
+        ni["verified"] = bool(all((a_[k].view(np.uint32) == b_[k].view(np.uint32)).all() if a_[k].dtype == np.float32 else (a_[k] == b_[k]).all()
+                                  for k in ("idx_local", "iso", "qrows", "a", "b", "err")))
+        out["single_image"]["natural_image"] = ni
     img0 = run.dev_in[0].cpu().numpy() if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None
     run.close()
 

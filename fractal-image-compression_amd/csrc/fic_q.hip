@@ -21,10 +21,13 @@
 // exactly; since L(X) >= m - E, an unflagged later pair Y (|acc_Y| <= theta) has  L(Y) <= |acc_Y| + E <= (1 - 2^-18) L(X):
 // its |r| is strictly smaller than X's, its error not smaller, and -- coming later -- it cannot win a tie (FC:627 strict <).
 // Chunk start.  The first domain tile of a pool chunk seeds theta from the tile's LARGEST |acc| (pair X*), which may have a
-// higher index than pairs it prunes; that is sound when L(X*) >= 0.26 n >= 0.25 (1 + 2^-20) rem, because then |r_X*| >= 1/4
-// and 1 - r^2 of a pair with r^2 smaller by 2^-17 relative is a strictly larger float, so the pruned pair's error is STRICTLY
-// larger and the index order is irrelevant.  Ranges whose first tile has no such pair (low contrast) evaluate the whole first
-// tile, as the older sweeps do for every range.  Candidate 0 is always evaluated (the global fallback winner, FC:613-632: every
+// higher index than pairs it prunes; that is sound when L(X*) >= 0.26 rem >= 0.25 (1 + 2^-20) rem (rem = the range block's
+// `varianzRange`, FC:671: r = kovarianz / (rem sqrt(var)) = L / rem), because then |r_X*| >= 1/4 and 1 - r^2 of a pair with r^2
+// smaller by 2^-17 relative is a strictly larger float, so the pruned pair's error is STRICTLY larger and the index order is
+// irrelevant.  The bound is per range block (round 3; before: 0.26 n for all of them, n - 1 being the largest possible rem --
+// on natural images the many smooth blocks, whose L is small in absolute terms, then never seeded and evaluated the whole first
+// tile of every pool chunk).  Ranges whose first tile has no such pair evaluate that whole tile, as the older sweeps do for
+// every range.  Candidate 0 is always evaluated (the global fallback winner, FC:613-632: every
 // pair with r^2 rounding 1 - r^2 to 1, flat blocks included, ties with it at error = rem^2 and loses on index).
 //
 // The 8 isometries at half the matrix work ("folded" mode, B = 8 / 16).  The isometries come in four pairs {k, k'} that differ
@@ -59,6 +62,7 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 #define FIC_Q_TAU_ALL 3.0e38f              // "never flagged": above the test value of any pair (grey: L <= 16 * 255; joint RGB, where the
                                            //   operand is greyD / vD with vD as small as 1: ~1e8)
 #define FIC_Q_TAU_NONE (-1.0f)             // nothing evaluated yet: every real pair of the tile is flagged
+#define FIC_Q_LMIN 0.26f                   // a pair with L >= 0.26 rem has |r| >= 1/4: it prunes in any index order (header, "Chunk start")
 #define FIC_Q_ECOEF 7.0e-4f                // >= 2^-10.5
 #define FIC_Q_EABS 1.6e-5f
 #define FIC_Q_QCAP 1280                    // queue entries per wave: one tile can flag at most 1024 pairs
@@ -622,7 +626,6 @@ struct QArgs {
     const int16_t* rgb_rng;          // MODE 3 (joint RGB): greyR_i [N_r][n], R+G+B per pool pixel [N_d][n], pool statistics
     const uint16_t* rgb_pool;
     const FicRgbDomStat* rgb_dst;
-    float lmin;                      // L of a pair that prunes regardless of index order: 0.26 x the largest possible `rem`
     unsigned long long* stats;       // optional [8]: tile epilogues, tiles with flagged pairs, queued entries, waves; of every
                                      //   64th wave: shader-clock cycles and 100 MHz ticks it was alive (summed), their number
     int Nd, Nd_pad, Nr, Nr_pad, n, lgn, W, H, Rw;
@@ -674,6 +677,16 @@ template <int MODE> struct QMode {
 // first isometry of column sub-index c (MODE 2: of the pair {0,2}, {1,3}, {4,5}, {6,7})
 template <int MODE> __device__ __forceinline__ int q_col_iso(int c) { return MODE == 2 ? (c == 0 ? 0 : (c == 1 ? 1 : (c == 2 ? 4 : 6))) : c; }
 
+// Lexicographic (error, candidate) minimum into a range's search key.  The 8-byte atomic executes at the memory side, where
+// updates of ONE address serialise (~12 ns each, chip-wide): on natural images a smooth range block has thousands of near-equal
+// candidates, every one evaluated exactly, nearly none an improvement -- so the key is read first (a device-scope load: past
+// the L1, from L2; a stale value is an OLDER one, i.e. larger: the atomic is then issued needlessly, never skipped wrongly)
+// and the atomic issued only for a candidate that beats it.
+__device__ __forceinline__ void q_key_min(unsigned long long* keyp, unsigned long long best)
+{
+    if (best < __hip_atomic_load(keyp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(keyp, best);
+}
+
 // Exact evaluation of the queued entries, one per lane: kovarianz = sum r*d - rM*sum(d) - dM*rem (exact integers), then
 // getErrorVarianceCovariance FC:674-683 and the strict-'<' scan of FC:619-632 as a lexicographic atomicMin.  A MODE 2 entry
 // is an isometry pair: both copies are evaluated against the one domain block.
@@ -717,7 +730,7 @@ __device__ __forceinline__ void q_flush(const QArgs& A, const uint32_t* myq, int
                 float r = (rs.rem == 0 || ds.vD == 0) ? 0.0f : __fdiv_rn(kov, __fmul_rn(vRf, (float)ds.vD));
                 r = __fmul_rn(r, r);
                 const float e = __fmul_rn(__fmul_rn(vRf, vRf), __fsub_rn(1.0f, r));
-                atomicMin(&keyp[col], ((unsigned long long)f32_orderable(e) << 32) | d);
+                q_key_min(&keyp[col], ((unsigned long long)f32_orderable(e) << 32) | d);
                 continue;
             }
             const int j = col >> CSHIFT, k = q_col_iso<MODE>(col & ((1 << CSHIFT) - 1));
@@ -753,7 +766,7 @@ __device__ __forceinline__ void q_flush(const QArgs& A, const uint32_t* myq, int
                 const unsigned long long b2 = ((unsigned long long)f32_orderable(err2) << 32) | (d * (uint32_t)NISO + (uint32_t)k2);
                 best = b2 < best ? b2 : best;
             }
-            atomicMin(&keyp[j], best);
+            q_key_min(&keyp[j], best);
         }
     }
 }
@@ -880,7 +893,7 @@ __global__ __launch_bounds__(64 * FIC_Q_WPG, NK == 4 ? FIC_Q_WAVES_B8 : (NK < 4 
             for (int m = 0; m < NK; m++) rb[ci][m] = rp[(ci * NK + m) * 64];
     }
     // per lane and column tile: the range behind the column, its theta, its error bound
-    float tau[CTW], E[CTW];
+    float tau[CTW], E[CTW], lmn[CTW];                        // lmn: L from which a pair of this range prunes in ANY index order (header)
     uint32_t okbits = 0, raise = 0;                          // bit ci: the column's range exists / may raise theta (rem != 0)
 #pragma unroll
     for (int ci = 0; ci < CTW; ci++) {
@@ -891,6 +904,7 @@ __global__ __launch_bounds__(64 * FIC_Q_WPG, NK == 4 ? FIC_Q_WAVES_B8 : (NK < 4 
         E[ci] = ok ? A.rngE[(size_t)plane * A.Nr_pad + j] : 0.0f;
         // rem == 0: error 0 for every block (FC:677) -> only candidate 0 can win; padding: never flagged
         tau[ci] = (ok && rem != 0 && !A.dbg_noflag) ? FIC_Q_TAU_NONE : FIC_Q_TAU_ALL;
+        lmn[ci] = FIC_Q_LMIN * (float)rem;
         okbits |= ok ? 1u << ci : 0u;
         raise |= (ok && rem != 0) ? 1u << ci : 0u;
     }
@@ -900,7 +914,6 @@ __global__ __launch_bounds__(64 * FIC_Q_WPG, NK == 4 ? FIC_Q_WAVES_B8 : (NK < 4 
     // the prefetched fragment loads as well: s_waitcnt vmcnt(0))
     const uint32_t AS4* pflat = (const uint32_t AS4*)(uintptr_t)(A.dflat + (size_t)plane * A.ndtiles_alloc);
     const v16f zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    const float lmin = A.lmin;                               // L of a pair that prunes regardless of index order (header)
     int qn = 0;                                              // queued entries (wave-uniform)
     unsigned st_slow = 0, st_pairs = 0;                      // instrumentation (wave-uniform; reported when A.stats is set)
 
@@ -916,9 +929,9 @@ __global__ __launch_bounds__(64 * FIC_Q_WPG, NK == 4 ? FIC_Q_WAVES_B8 : (NK < 4 
     };
     // A tile with flagged entries (or a chunk's first tile): queue the entries, raise theta.
     //   theta moves three ways: (1) FIRST: seeded from the tile's largest test value per range -- out of index order, hence
-    //   only when that pair's L >= lmin (header); (2) from the flagged entries of this tile (they have lower indices than
+    //   only when that pair's L >= lmn = 0.26 rem (header); (2) from the flagged entries of this tile (they have lower indices than
     //   everything still to come in this chunk); (3) from theta_g, the best level any wave has published for the range --
-    //   other chunks, any index order, hence published only for pairs with L >= lmin.
+    //   other chunks, any index order, hence published only for pairs with L >= lmn.
     auto slow_tile = [&](const v16f& acc, const v16f& acc2, float mx, int ci, int dt, bool first) __attribute__((always_inline)) {
         // only zeros flagged (theta still "none"): an all-flat tile seen before anything was evaluated needs nothing
         if (!first && __builtin_amdgcn_ballot_w64(mx > 0.0f) == 0 && pflat[dt] != 0u) return;
@@ -935,7 +948,7 @@ __global__ __launch_bounds__(64 * FIC_Q_WPG, NK == 4 ? FIC_Q_WAVES_B8 : (NK < 4 
         const uint32_t ent0 = (uint32_t)(dt * 32 + 4 * half) | ((uint32_t)colw << 24);   // entry of element 0; element e adds its row
         if (first) {                                         // (1)
             const float lo = __fsub_rn(q_share_max<MODE>(ok ? mx : 0.0f), E[ci]);
-            if (mayraise && lo >= lmin) tau[ci] = fmaxf(tau[ci], __fsub_rn(__fmul_rn(lo, FIC_Q_LEVEL), E[ci]));
+            if (mayraise && lo >= lmn[ci]) tau[ci] = fmaxf(tau[ci], __fsub_rn(__fmul_rn(lo, FIC_Q_LEVEL), E[ci]));
         }
         // candidate 0 = (block 0, copy 0): always evaluated (MODE 2: with its partner, copy 2)
         const bool cand0 = first && dt == 0 && half == 0 && ok && (jcol & ((1 << CSHIFT) - 1)) == 0;
@@ -968,7 +981,7 @@ __global__ __launch_bounds__(64 * FIC_Q_WPG, NK == 4 ? FIC_Q_WAVES_B8 : (NK < 4 
         if (mayraise && lo2 >= 0.0f) {
             const float lb = __fsub_rn(__fmul_rn(lo2, FIC_Q_LEVEL), E[ci]);
             tau[ci] = fmaxf(tau[ci], lb);
-            if (MULTI && lo2 >= lmin && half == 0 && (jcol & ((1 << CSHIFT) - 1)) == 0) atomicMax(&thg[jg], f32_orderable(lb));
+            if (MULTI && lo2 >= lmn[ci] && half == 0 && (jcol & ((1 << CSHIFT) - 1)) == 0) atomicMax(&thg[jg], f32_orderable(lb));
         }
         if (MULTI && mayraise && g != 0u) tau[ci] = fmaxf(tau[ci], f32_from_orderable(g));
         // the fill count after this tile (LDS operations of a wave complete in order); one tile adds at most 1024 entries
@@ -1149,7 +1162,7 @@ __global__ __launch_bounds__(64 * FIC_Q_WPG, NK == 4 ? FIC_Q_WAVES_B8 : 1) void 
 #pragma unroll
             for (int m = 0; m < NK; m++) rb[ci][m] = rp[(ci * NK + m) * 64];
     }
-    float tau[CU], E[CU];
+    float tau[CU], E[CU], lmn[CU];
     uint32_t okbits = 0, raise = 0;
 #pragma unroll
     for (int cj = 0; cj < CU; cj++) {
@@ -1158,13 +1171,13 @@ __global__ __launch_bounds__(64 * FIC_Q_WPG, NK == 4 ? FIC_Q_WAVES_B8 : 1) void 
         const int rem = ok ? rst[j].rem : 0;
         E[cj] = ok ? A.rngE[(size_t)plane * A.Nr_pad + j] : 0.0f;
         tau[cj] = (ok && rem != 0 && !A.dbg_noflag) ? FIC_Q_TAU_NONE : FIC_Q_TAU_ALL;
+        lmn[cj] = FIC_Q_LMIN * (float)rem;
         okbits |= ok ? 1u << cj : 0u;
         raise |= (ok && rem != 0) ? 1u << cj : 0u;
     }
     const v4i* pa = A.poolQ + (size_t)plane * A.ndtiles_alloc * NK * 64 + lane;
     const uint32_t AS4* pflat = (const uint32_t AS4*)(uintptr_t)(A.dflat + (size_t)plane * A.ndtiles_alloc);
     const v4f zero = {0, 0, 0, 0};
-    const float lmin = A.lmin;
     int qn = 0;
     unsigned st_slow = 0, st_pairs = 0;
 
@@ -1186,9 +1199,9 @@ __global__ __launch_bounds__(64 * FIC_Q_WPG, NK == 4 ? FIC_Q_WAVES_B8 : 1) void 
         const int jg = ctw0 * 32 + colw;                     // the column's range block (valid when ok)
         const uint32_t g = (MULTI && mayraise) ? thg[jg] : 0u;
         const uint32_t ent0 = (uint32_t)(dt * 32 + 4 * g4) | ((uint32_t)colw << 24);     // entry of element 0; element e adds 16 (e >> 2) + (e & 3)
-        if (first) {                                         // (1) out-of-order seed, only from a pair with L >= lmin
+        if (first) {                                         // (1) out-of-order seed, only from a pair with L >= lmn
             const float lo = __fsub_rn(q16_share_max(ok ? mx : 0.0f), E[cj]);
-            if (mayraise && lo >= lmin) tau[cj] = fmaxf(tau[cj], __fsub_rn(__fmul_rn(lo, FIC_Q_LEVEL), E[cj]));
+            if (mayraise && lo >= lmn[cj]) tau[cj] = fmaxf(tau[cj], __fsub_rn(__fmul_rn(lo, FIC_Q_LEVEL), E[cj]));
         }
         const bool cand0 = first && dt == 0 && g4 == 0 && ok;                // candidate 0 = block 0: always evaluated
         uint32_t hm = 0;
@@ -1214,7 +1227,7 @@ __global__ __launch_bounds__(64 * FIC_Q_WPG, NK == 4 ? FIC_Q_WAVES_B8 : 1) void 
         if (mayraise && lo2 >= 0.0f) {
             const float lb = __fsub_rn(__fmul_rn(lo2, FIC_Q_LEVEL), E[cj]);
             tau[cj] = fmaxf(tau[cj], lb);
-            if (MULTI && lo2 >= lmin && g4 == 0) atomicMax(&thg[jg], f32_orderable(lb));
+            if (MULTI && lo2 >= lmn[cj] && g4 == 0) atomicMax(&thg[jg], f32_orderable(lb));
         }
         if (MULTI && mayraise && g != 0u) tau[cj] = fmaxf(tau[cj], f32_from_orderable(g));           // (3)
         const int tot = __builtin_amdgcn_readfirstlane((int)*(volatile __attribute__((address_space(3))) uint32_t*)(__attribute__((address_space(3))) uint32_t*)myqn);
@@ -1389,7 +1402,6 @@ int fic_launch_sweep_q(const FicBuffers& b, const void* poolQ, const void* dflat
     const int CT = fic_q_ct(g.B);
     A.nctg = (ct_end - ct_begin + CT - 1) / CT;
     A.planes = g.planes;
-    A.lmin = 0.26f * (float)g.n;
     A.rgb_rng = nullptr; A.rgb_pool = nullptr; A.rgb_dst = nullptr;
     // the loop reads up to ndtiles_loop + prefetch distance tiles; chunks must be whole unrolled iterations
     if (ct_begin + A.nctg * CT > nct_alloc || g.Nd >= (1 << 24) || A.ndtiles_loop + unroll > ndtiles_alloc || tiles_per_chunk % unroll)
@@ -1409,7 +1421,7 @@ int fic_launch_sweep_q(const FicBuffers& b, const void* poolQ, const void* dflat
 //   r = kovarianz / (vR * vD)  (0 when vR == 0 or vD == 0),   error = vR^2 (1 - r^2)
 // i.e. the grey formulas with rem := vR and q := kovarianz / vD.  So the domain operand is A[d][i] = f16(greyD_i / vD) (zero for
 // vD == 0), the range operand B[i][c] = f16(greyR_i) (integers in [-765, 765]: exact), acc ~ q, and theta / the queue / the
-// any-order rules are those of the grey sweep with lmin = 0.26 * 3n (vR < 3n).  Differences:
+// any-order rules are those of the grey sweep (L >= 0.26 vR of the range block; qst[].rem = vR).  Differences:
 //  * ||A_d|| is not 1: |acc - q| <= 2^-11 * 1.07 * ||greyR|| * ||A_d||, bounded per range with Amax = max_d ||A_d|| (the blocks
 //    that can win have small vD and large norm, so the bound is tight where it matters);
 //  * Java accumulates kovarianz in f32 in the order i = 0..n-1 and the sums exceed 2^24: the value the reference compares is
@@ -1531,7 +1543,6 @@ int fic_launch_rgbq(const uint16_t* pool_sum, const FicRgbDomStat* pool_st, cons
     A.rngQ = (const v4i*)rngQ; A.rngC = nullptr; A.rng_st = (const FicRngStat*)qst; A.rngE = (const float*)rngE; A.key = key;
     A.theta_g = (uint32_t*)theta_g;
     A.rgb_rng = rng_t; A.rgb_pool = pool_sum; A.rgb_dst = pool_st;
-    A.lmin = 0.26f * 3.0f * (float)g.n;
     A.Nd = g.Nd; A.Nd_pad = g.Nd; A.Nr = g.Nr; A.Nr_pad = g.Nr; A.n = g.n; A.lgn = g.lgn; A.W = g.W; A.H = g.H; A.Rw = g.Rw;
     const int unroll = FIC_Q_UNROLL;
     A.ndtiles = ndtiles; A.ndtiles_loop = (ndtiles + unroll - 1) / unroll * unroll; A.ndtiles_alloc = ndtiles_alloc; A.nct_alloc = nct_alloc;

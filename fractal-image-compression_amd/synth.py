@@ -36,6 +36,20 @@ def image_s(w, h, seed):
     return s.astype(np.uint8)
 
 
+def enlarge(base, w, h, oy=0, ox=0):
+    """`base` (uint8 [H0, W0], continued periodically) enlarged bilinearly to w x h, shifted by (oy, ox) base pixels: a
+    smooth natural image of any size from a small one, without the exact duplicate blocks tiling would give."""
+    H0, W0 = base.shape
+    ys = np.arange(h) * (H0 / float(h)) + oy
+    xs = np.arange(w) * (W0 / float(w)) + ox
+    y0, x0 = np.floor(ys).astype(np.int64), np.floor(xs).astype(np.int64)
+    wy, wx = (ys - y0)[:, None], (xs - x0)[None, :]
+    a = base.astype(np.float64)
+    at = lambda yy, xx: a[np.ix_(yy % H0, xx % W0)]
+    v = (1 - wy) * ((1 - wx) * at(y0, x0) + wx * at(y0, x0 + 1)) + wy * ((1 - wx) * at(y0 + 1, x0) + wx * at(y0 + 1, x0 + 1))
+    return np.clip(np.rint(v), 0, 255).astype(np.uint8)
+
+
 def image(kind, w, h, seed):
     return image_u(w, h, seed) if kind.upper() == "U" else image_s(w, h, seed)
 

@@ -493,7 +493,7 @@ def test_seeded_fuzz_geometries_windows_sweeps(oracle):
         square_full = (Dw == Dh) and rng.random() < 0.5
         wK = Dw if square_full else int(rng.integers(1, min(Dw, Dh, 17) + 1))
         n_iso = int(rng.choice([1, 8]))
-        kind = rng.choice(["U", "S", "flat", "ramp"])
+        kind = rng.choice(["U", "S", "flat", "ramp", "smooth", "lowc"])
         seed = int(rng.integers(1, 1 << 30))
         if kind == "U":
             g = synth.image_u(w, h, seed)
@@ -501,6 +501,14 @@ def test_seeded_fuzz_geometries_windows_sweeps(oracle):
             g = synth.image_s(w, h, seed)
         elif kind == "flat":
             g = np.full((h, w), seed % 256, np.uint8)
+        elif kind == "smooth":                          # slow waves of a few grey levels + noise: smooth blocks of natural images
+            yy, xx = np.mgrid[0:h, 0:w]
+            amp = 1.0 + (seed % 12)
+            g = np.rint(128 + amp * np.sin(xx / (5.0 + seed % 7)) + amp * np.cos(yy / (4.0 + seed % 5))
+                        + np.random.default_rng(seed).integers(-1, 2, (h, w))).astype(np.uint8)
+        elif kind == "lowc":                            # a few grey levels of texture on steps
+            yy, xx = np.mgrid[0:h, 0:w]
+            g = (60 + (seed % 130) + xx // 29 + yy // 41 + np.random.default_rng(seed).integers(0, 2 + seed % 4, (h, w))).astype(np.uint8)
         else:
             g = ((np.arange(w)[None, :] * 3 + np.arange(h)[:, None] * 5 + seed) % 256).astype(np.uint8)
         ref = oracle.encode_gray(oracle.gray_to_argb(g), w, h, B, wK, n_iso)
@@ -514,7 +522,7 @@ def test_seeded_fuzz_geometries_windows_sweeps(oracle):
             if B >= 8 and n_iso == 1:
                 sweeps.append(16)                       # k_sweep_q16: "sweep" = 6 with the 16x16x32 MFMA shape forced
         for sweep in sweeps:
-            got = fic_amd.encode_gray(g, B, wK, n_iso, sweep=6 if sweep == 16 else sweep, chunks=int(rng.integers(0, 4)) if sweep >= 2 else 0,
+            got = fic_amd.encode_gray(g, B, wK, n_iso, sweep=6 if sweep == 16 else sweep, chunks=int(rng.choice([0, 1, 2, 3, 7, 40, 10000])) if sweep >= 2 else 0,
                                       q_shape=1 if sweep == 16 else 0)
             try:
                 _assert_same(oracle, got, ref)

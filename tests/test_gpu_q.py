@@ -32,6 +32,15 @@ def _low_contrast(size, seed):
     return (100 + (x // 37) + (y // 53) + rng.integers(-2, 3, (size, size))).astype(np.uint8)
 
 
+def _smooth_low(size, seed, amp):
+    """Slow waves of a few grey levels + +-1 noise: smooth blocks as natural images have them, ||r - rM|| of 3..25 -- the best
+    pair's L lies between 0.26 rem (from where a pair may seed / publish theta in any index order) and 0.26 n (round 2's bound)."""
+    rng = np.random.default_rng(seed)
+    y, x = np.mgrid[0:size, 0:size]
+    return np.rint(120 + amp * np.sin(x / 9.0) + amp * np.cos(y / 7.0) + 0.5 * amp * np.sin((x + 2 * y) / 23.0)
+                   + rng.integers(-1, 2, (size, size))).astype(np.uint8)
+
+
 def _duplicates(size, seed):
     """A 16x16 tile repeated everywhere: every domain block occurs dozens of times (exact ties, lowest index must win)."""
     rng = np.random.default_rng(seed)
@@ -54,6 +63,8 @@ IMAGES = {
     "flat64": np.full((64, 64), 77, np.uint8),
     "letterbox": _letterbox(192, 5, 40),
     "lowcontrast": _low_contrast(160, 6),
+    "smooth3": _smooth_low(160, 9, 3.0),
+    "smooth8": _smooth_low(128, 10, 8.0),
     "duplicates": _duplicates(128, 7),
     "onenoisy": _one_noisy_block(128, 8),
     "ramp": ((np.arange(160)[None, :] * 3 + np.arange(160)[:, None] * 5) % 256).astype(np.uint8),
@@ -95,7 +106,8 @@ def test_q_sweep_matches_oracle(oracle, name, B, n_iso):
         _check(oracle, got, ref)
 
 
-@pytest.mark.parametrize("name,B,n_iso", [("lowcontrast", 8, 8), ("letterbox", 8, 1), ("duplicates", 8, 8), ("S128", 4, 8), ("U128", 16, 1)])
+@pytest.mark.parametrize("name,B,n_iso", [("lowcontrast", 8, 8), ("letterbox", 8, 1), ("duplicates", 8, 8), ("S128", 4, 8), ("U128", 16, 1),
+                                          ("smooth3", 8, 8), ("smooth8", 8, 1), ("smooth3", 4, 1), ("lena256", 8, 8)])
 def test_q_sweep_many_chunk_starts(oracle, name, B, n_iso):
     """Up to one chunk per domain tile: every tile is a chunk's first tile (out-of-order seeding everywhere)."""
     g = IMAGES[name]

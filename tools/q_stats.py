@@ -1,4 +1,6 @@
-"""Timing + k_sweep_q counters for a list of cases: W,B,iso,planes[,dist[,sweep[,chunks]]] (defaults: U, 6, auto)."""
+"""Timing + k_sweep_q counters for a list of cases: W,B,iso,planes[,dist[,sweep[,chunks]]] (defaults: U, 6, auto).
+dist: U = iid bytes, S = flat tiles + noise, L = LenaGrey (tests/golden, 256x256) tiled with a per-plane shift (exact duplicate
+blocks: ties everywhere), N = LenaGrey enlarged bilinearly to W x W and shifted per plane (a smooth natural image, no duplicates)."""
 import os
 import sys
 
@@ -10,9 +12,26 @@ import fic_amd
 from fic_amd import synth
 
 
+_LENA = None
+
+
+def lena(W, seed, enlarge):
+    global _LENA
+    if _LENA is None:
+        _LENA = np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "lena_grey_256.npy"))
+    oy, ox = (seed * 7) % 256, (seed * 13) % 256
+    if not enlarge:
+        t = np.tile(_LENA, (W // 256 + 2, W // 256 + 2))
+        return np.ascontiguousarray(t[oy:oy + W, ox:ox + W])
+    return synth.enlarge(_LENA, W, W, oy, ox)
+
+
 def run(W, B, n_iso, planes, dist="U", sweep=6, chunks=0, reps=5):
-    f = synth.image_u if dist == "U" else synth.image_s
-    g = np.stack([f(W, W, 100 + 3 * p) for p in range(planes)])
+    if dist in ("L", "N"):
+        g = np.stack([lena(W, 100 + 3 * p, dist == "N") for p in range(planes)])
+    else:
+        f = synth.image_u if dist == "U" else synth.image_s
+        g = np.stack([f(W, W, 100 + 3 * p) for p in range(planes)])
     d = torch.from_numpy(g).cuda()
     enc = fic_amd.Encoder(W, W, B, None, n_iso, planes)
     enc.set_gray(d)
