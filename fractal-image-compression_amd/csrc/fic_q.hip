@@ -20,6 +20,10 @@
 // theta of a range only ever takes values  fl(fl((m - E) * (1 - 2^-17)) - E)  where m = |acc_X| of a pair X that IS evaluated
 // exactly; since L(X) >= m - E, an unflagged later pair Y (|acc_Y| <= theta) has  L(Y) <= |acc_Y| + E <= (1 - 2^-18) L(X):
 // its |r| is strictly smaller than X's, its error not smaller, and -- coming later -- it cannot win a tie (FC:627 strict <).
+// In general: a pair Y may be skipped whenever SOME pair X of the same range has (error_X, index_X) < (error_Y, index_Y)
+// lexicographically -- then Y is not the minimum, whether or not X itself is ever evaluated (if X is skipped, it is not the
+// minimum either); the true minimum is never skipped, and it is evaluated exactly.  X with a lower index and L(Y) <=
+// (1 - 2^-18) L(X) is such a pair; so is X in any index order once its error is STRICTLY smaller (next paragraph).
 // Chunk start.  The first domain tile of a pool chunk seeds theta from the tile's LARGEST |acc| (pair X*), which may have a
 // higher index than pairs it prunes; that is sound when L(X*) >= 0.26 rem >= 0.25 (1 + 2^-20) rem (rem = the range block's
 // `varianzRange`, FC:671: r = kovarianz / (rem sqrt(var)) = L / rem), because then |r_X*| >= 1/4 and 1 - r^2 of a pair with r^2
@@ -681,7 +685,7 @@ template <int MODE> __device__ __forceinline__ int q_col_iso(int c) { return MOD
 // updates of ONE address serialise (~12 ns each, chip-wide): on natural images a smooth range block has thousands of near-equal
 // candidates, every one evaluated exactly, nearly none an improvement -- so the key is read first (a device-scope load: past
 // the L1, from L2; a stale value is an OLDER one, i.e. larger: the atomic is then issued needlessly, never skipped wrongly)
-// and the atomic issued only for a candidate that beats it.
+// and the atomic issued only for a candidate that beats it (q_flush's grey path does the same with the read hoisted above its gathers).
 __device__ __forceinline__ void q_key_min(unsigned long long* keyp, unsigned long long best)
 {
     if (best < __hip_atomic_load(keyp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(keyp, best);
@@ -735,6 +739,7 @@ __device__ __forceinline__ void q_flush(const QArgs& A, const uint32_t* myq, int
             }
             const int j = col >> CSHIFT, k = q_col_iso<MODE>(col & ((1 << CSHIFT) - 1));
             const int k2 = k == 0 ? 2 : (k == 1 ? 3 : k + 1);                       // MODE 2: the pair's second isometry
+            const unsigned long long cur = __hip_atomic_load(&keyp[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // q_key_min's read, issued with the gathers
             const FicRngStat rs = rst[j];
             const int Sd = (int)pst[d].sum;
             const double s64 = p64[d];
@@ -766,7 +771,7 @@ __device__ __forceinline__ void q_flush(const QArgs& A, const uint32_t* myq, int
                 const unsigned long long b2 = ((unsigned long long)f32_orderable(err2) << 32) | (d * (uint32_t)NISO + (uint32_t)k2);
                 best = b2 < best ? b2 : best;
             }
-            q_key_min(&keyp[j], best);
+            if (best < cur) atomicMin(&keyp[j], best);
         }
     }
 }
@@ -1006,11 +1011,31 @@ __global__ __launch_bounds__(64 * FIC_Q_WPG, NK == 4 ? FIC_Q_WAVES_B8 : (NK < 4 
     // as soon as the last MFMAs that read `ac` have been issued (column tile CTW-1), `ac` is reloaded with tile dt + 2, which
     // is first needed at the end of the NEXT step: every load has CTW + 1 tile epilogues (a step and a quarter) to land.
     v4i a0[NK], a1[NK];
+    v16f acc, acc2 = zero;
+    // Prefix seed (pool chunks after the first).  theta may be the level of ANY pair X with a LOWER index than the pairs it
+    // prunes, evaluated or not: if X was pruned itself, then by a pair that beats or ties-and-precedes it, and that pair beats a
+    // later Y with L(Y) <= (1 - 2^-18) L(X) all the same (header, "Invariant").  Domain tile 0 holds the lowest indices of the
+    // pool, so a chunk that starts further in takes its first theta from tile 0's largest test value per range -- one tile of
+    // extra matrix work per chunk -- instead of starting at "none", where the chunk's whole first tile is evaluated exactly for
+    // every range that cannot seed out of order (L < 0.26 rem: the smooth blocks of natural images).
+    if constexpr (MULTI) {
+        if (dt0 != 0) {                                      // (wave-uniform)
+#pragma unroll
+            for (int m = 0; m < NK; m++) a0[m] = pa[(size_t)m * 64];
+#pragma unroll
+            for (int ci = 0; ci < CTW; ci++) {
+                tile_mfma(a0, rb[ci], acc, acc2);
+                const float mx = FOLD ? max16_sum(acc, acc2) : max16_abs(acc);
+                const bool ok = (okbits >> ci) & 1u, mayraise = (raise >> ci) & 1u;
+                const float lo = __fsub_rn(q_share_max<MODE>(ok ? mx : 0.0f), E[ci]);
+                if (mayraise && lo > 0.0f) tau[ci] = fmaxf(tau[ci], __fsub_rn(__fmul_rn(lo, FIC_Q_LEVEL), E[ci]));
+            }
+        }
+    }
 #pragma unroll
     for (int m = 0; m < NK; m++) a0[m] = pa[((size_t)dt0 * NK + m) * 64];
 #pragma unroll
     for (int m = 0; m < NK; m++) a1[m] = pa[((size_t)(dt0 + 1) * NK + m) * 64];
-    v16f acc, acc2 = zero;
     tile_mfma(a0, rb[0], acc, acc2);
 
     // one domain tile (the fragment store has spare zero tiles behind the pool for the loop's overrun and the prefetch)
@@ -1246,11 +1271,25 @@ __global__ __launch_bounds__(64 * FIC_Q_WPG, NK == 4 ? FIC_Q_WAVES_B8 : 1) void 
     };
 
     v4i a0[NK], a1[NK];
+    v4f x0, x1;
+    if constexpr (MULTI) {                                   // prefix seed from domain tile 0, as in k_sweep_q
+        if (dt0 != 0) {
+#pragma unroll
+            for (int m = 0; m < NK; m++) a0[m] = pa[(size_t)m * 64];
+#pragma unroll
+            for (int cj = 0; cj < CU; cj++) {
+                unit_mfma(a0, cj, x0, x1);
+                const float mx = max8_abs(x0, x1);
+                const bool ok = (okbits >> cj) & 1u, mayraise = (raise >> cj) & 1u;
+                const float lo = __fsub_rn(q16_share_max(ok ? mx : 0.0f), E[cj]);
+                if (mayraise && lo > 0.0f) tau[cj] = fmaxf(tau[cj], __fsub_rn(__fmul_rn(lo, FIC_Q_LEVEL), E[cj]));
+            }
+        }
+    }
 #pragma unroll
     for (int m = 0; m < NK; m++) a0[m] = pa[((size_t)dt0 * NK + m) * 64];
 #pragma unroll
     for (int m = 0; m < NK; m++) a1[m] = pa[((size_t)(dt0 + 1) * NK + m) * 64];
-    v4f x0, x1;
     unit_mfma(a0, 0, x0, x1);
     auto step = [&](int dt, v4i (&ac)[NK], const v4i (&an)[NK], const bool first) __attribute__((always_inline)) {
 #pragma unroll

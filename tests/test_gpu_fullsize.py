@@ -100,7 +100,7 @@ def test_cfg4_size_reference_algorithm_and_S_image(oracle):
 
 @pytest.mark.parametrize("size,B,n_iso,dist", [(4096, 8, 8, "U"), (4096, 8, 1, "S"), (2048, 4, 1, "U"), (2048, 4, 8, "S"),
                                                 (4096, 16, 1, "S"), (2048, 16, 8, "U"), (2048, 8, 8, "lena"), (2048, 8, 1, "lena"),
-                                                (1024, 4, 8, "lena")])
+                                                (1024, 4, 8, "lena"), (2048, 8, 8, "nat"), (2048, 4, 1, "nat"), (1024, 16, 8, "nat")])
 def test_whole_codebook_at_full_size_valu_equals_matrix_core(size, B, n_iso, dist):
     """Every range block of a BASELINE-sized image through two independent sweeps -- the VALU kernel (integer dot
     products, range blocks in lanes) and the matrix-core kernel (bf16 / i8 MFMA tiles, deferred exact epilogue): the
@@ -111,6 +111,10 @@ def test_whole_codebook_at_full_size_valu_equals_matrix_core(size, B, n_iso, dis
         from conftest import GOLDEN
         base = np.load(os.path.join(GOLDEN, "lena_grey_256.npy"))
         g = np.ascontiguousarray(np.tile(base, (size // 256 + 1, size // 256 + 1))[37:37 + size, 101:101 + size])
+    elif dist == "nat":                                 # LenaGrey enlarged bilinearly: smooth blocks, thousands of near-equal candidates,
+        import os                                       # best L of many range blocks below 0.26 n
+        from conftest import GOLDEN
+        g = synth.enlarge(np.load(os.path.join(GOLDEN, "lena_grey_256.npy")), size, size, 11, 5)
     else:
         g = (synth.image_u if dist == "U" else synth.image_s)(size, size, synth.SEEDS["cfg4"] + B + n_iso)
     res = {}
@@ -130,7 +134,7 @@ def test_whole_codebook_at_full_size_valu_equals_matrix_core(size, B, n_iso, dis
     assert runs[0] == runs[1]
     # not a degenerate comparison: the codebook uses many different domain blocks (and isometries); the S images are
     # mostly flat 32x32 tiles (rem == 0 -> index 0, FC:677), so only their noisy half spreads out
-    assert len(np.unique(res[2]["idx_local"])) > {"S": 10, "lena": 300, "U": 1000}[dist]   # (tiled Lena repeats itself)
+    assert len(np.unique(res[2]["idx_local"])) > {"S": 10, "lena": 300, "nat": 100, "U": 1000}[dist]   # (tiled Lena repeats itself)
     if n_iso == 8 and dist == "U":
         assert len(np.unique(res[2]["iso"])) == 8
 

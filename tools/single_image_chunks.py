@@ -7,11 +7,16 @@ import fic_amd
 from fic_amd import synth
 
 W = int(sys.argv[1]) if len(sys.argv) > 1 else 512
+dist = sys.argv[2] if len(sys.argv) > 2 else "U"          # U = iid bytes, N = LenaGrey (tests/golden) enlarged bilinearly
 out = {}
 for n_iso in (8, 1):
-    g = synth.image_u(W, W, synth.SEEDS["cfg2"])
+    if dist == "N":
+        import numpy as np
+        g = synth.enlarge(np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "lena_grey_256.npy")), W, W)
+    else:
+        g = synth.image_u(W, W, synth.SEEDS["cfg2"])
     d = torch.from_numpy(g[None]).cuda()
-    for chunks in (0, 2, 4, 6, 8, 10, 12, 16, 20, 24, 28, 36):
+    for chunks in (0, 4, 8, 12, 16, 20, 24, 28, 32, 36, 48):
         enc = fic_amd.Encoder(W, W, 8, None, n_iso)
         enc.set_gray(d)
         enc.set_option("sweep", 6)
@@ -30,6 +35,6 @@ for n_iso in (8, 1):
         e1.record(s)
         s.synchronize()
         ms, n = enc.sweep_time()
-        out[f"{W}_iso{n_iso}_chunks{chunks}"] = {"chunks_used": enc.info()["chunks"], "ms_per_encode": round(e0.elapsed_time(e1) / 200, 4), "sweep_ms": round(ms / n, 4)}
+        out[f"{W}_{dist}_iso{n_iso}_chunks{chunks}"] = {"chunks_used": enc.info()["chunks"], "ms_per_encode": round(e0.elapsed_time(e1) / 200, 4), "sweep_ms": round(ms / n, 4)}
         enc.close()
 print(json.dumps(out, indent=0))
