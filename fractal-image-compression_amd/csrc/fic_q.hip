@@ -88,6 +88,9 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 #define FIC_Q_WAVES_B4 3
 #endif
 __host__ __device__ constexpr int fic_q_ctw(int NK) { return NK == 4 ? FIC_Q_CTW_B8 : (NK < 4 ? FIC_Q_CTW_B4 : 2); }   // column tiles (x32 range copies) per wave
+#ifndef FIC_Q_SEED
+#define FIC_Q_SEED 1                       // pool chunks after the first take their first theta from domain tile 0 (0: A/B builds)
+#endif
 #define FIC_Q_UNROLL 2                     // domain tiles per iteration of the sweep loop (two fragment buffers swap roles)
 
 #ifndef FIC_Q_SHAPE16
@@ -1018,7 +1021,7 @@ __global__ __launch_bounds__(64 * FIC_Q_WPG, NK == 4 ? FIC_Q_WAVES_B8 : (NK < 4 
     // pool, so a chunk that starts further in takes its first theta from tile 0's largest test value per range -- one tile of
     // extra matrix work per chunk -- instead of starting at "none", where the chunk's whole first tile is evaluated exactly for
     // every range that cannot seed out of order (L < 0.26 rem: the smooth blocks of natural images).
-    if constexpr (MULTI) {
+    if constexpr (MULTI && FIC_Q_SEED) {
         if (dt0 != 0) {                                      // (wave-uniform)
 #pragma unroll
             for (int m = 0; m < NK; m++) a0[m] = pa[(size_t)m * 64];
@@ -1272,7 +1275,7 @@ __global__ __launch_bounds__(64 * FIC_Q_WPG, NK == 4 ? FIC_Q_WAVES_B8 : 1) void 
 
     v4i a0[NK], a1[NK];
     v4f x0, x1;
-    if constexpr (MULTI) {                                   // prefix seed from domain tile 0, as in k_sweep_q
+    if constexpr (MULTI && FIC_Q_SEED) {                     // prefix seed from domain tile 0, as in k_sweep_q
         if (dt0 != 0) {
 #pragma unroll
             for (int m = 0; m < NK; m++) a0[m] = pa[(size_t)m * 64];
