@@ -1,5 +1,5 @@
 """The literal BASELINE config 2 -- ONE 512x512 image, B = 8, full search, 8 isometries -- as 300 back-to-back encodes on one stream:
-run under `rocprofv3 --kernel-trace --stats` to see what the 5 kernels of an encode cost on the GPU against the time per encode
+run under `rocprofv3 --kernel-trace --stats` to see what the kernels of an encode (two for a launch this small: k_prep_q8 and the sweep with its finalising tail) cost on the GPU against the time per encode
 (what is left is dispatch gaps between dependent kernels)."""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
