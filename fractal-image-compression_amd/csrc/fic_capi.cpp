@@ -375,7 +375,8 @@ int q_prep(fic_ctx* c, int tile0, int tile1, hipStream_t s)
     }
     if (!c->q_rngC) HIP_TRY(hipMalloc(&c->q_rngC, P * g.Nr_pad * fic_q_cols_per_range(g.B, g.n_iso) * g.n));
     if (!c->q_E) HIP_TRY(hipMalloc(&c->q_E, P * g.Nr_pad * sizeof(float)));
-    if (!c->q_thg) HIP_TRY(hipMalloc(&c->q_thg, P * g.Nr_pad * sizeof(uint32_t)));
+    // (+ the padded column tiles behind the last plane: the sweep's fast path reads theta_g of every column it owns)
+    if (!c->q_thg) HIP_TRY(hipMalloc(&c->q_thg, (P * g.Nr_pad + (size_t)2 * q.CT * 32 + 64) * sizeof(uint32_t)));
     const int tsz = 64 * g.NR;
     const int grp0 = tile0 * tsz / 64, grp1 = tile1 * tsz / 64;      // 64-range groups covering the span
     if (fic_launch_q_prep(c->b, c->q_pool, c->q_flat, c->q_rng, c->q_rngC, c->q_E, c->q_thg, g, q.ndtiles_alloc, q.nct_alloc, grp0, grp1 - grp0, s))
@@ -427,6 +428,7 @@ int q_sweep(fic_ctx* c, int tile0, int tile1, hipStream_t s, int* nchunks_out, b
                            r_begin, r_count))
         return fail(FIC_E_HIP, "k_sweep_q launch failed");
     *nchunks_out = nchunks;
+    c->last_tiles_per_chunk = tiles_per_chunk;
     return FIC_OK;
 }
 
@@ -827,8 +829,11 @@ int fic_ctx_last_kernel(fic_ctx* c, char* out, int capacity)
     const FicGeom& g = c->g;
     const int NK = g.n / 16, kind = c->last_kind;
     const char* multi = c->last_chunks > 1 ? "true" : "false";
+    const bool shorts = kind == 6 && fic_q_multi_kind(c->last_chunks, c->last_tiles_per_chunk) == 2;    // short pool chunks: k_sweep_qs / k_sweep_q16s
     char buf[96];
-    if (kind == 6 && fic_q_shape16(g)) snprintf(buf, sizeof(buf), "k_sweep_q16<%d, %s>", NK, multi);
+    if (kind == 6 && fic_q_shape16(g) && shorts) snprintf(buf, sizeof(buf), "k_sweep_q16s<%d>", NK);
+    else if (kind == 6 && fic_q_shape16(g)) snprintf(buf, sizeof(buf), "k_sweep_q16<%d, %s>", NK, multi);
+    else if (kind == 6 && shorts) snprintf(buf, sizeof(buf), "k_sweep_qs<%d, %d>", NK, g.n_iso == 1 ? 0 : (g.B == 4 ? 1 : 2));
     else if (kind == 6) snprintf(buf, sizeof(buf), "k_sweep_q<%d, %d, %s>", NK, g.n_iso == 1 ? 0 : (g.B == 4 ? 1 : 2), multi);
     else if (kind == 5) snprintf(buf, sizeof(buf), "k_sweep_d4");
     else if (kind == 2) snprintf(buf, sizeof(buf), "k_sweep_fast");

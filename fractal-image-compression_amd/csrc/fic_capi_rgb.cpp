@@ -112,7 +112,7 @@ int rgb_q_setup(fic_rgb_ctx* c)
     A(hipMalloc(&q.rngQ, (size_t)q.nct_alloc * NK * 64 * 16));
     A(hipMalloc(&q.qst, (size_t)g.Nr * sizeof(FicRngStat)));
     A(hipMalloc(&q.rngE, (size_t)g.Nr * sizeof(float)));
-    A(hipMalloc(&q.theta_g, (size_t)g.Nr * sizeof(uint32_t)));
+    A(hipMalloc(&q.theta_g, (size_t)q.nct_alloc * 32 * sizeof(uint32_t)));     // per column incl. the padded column tiles (the sweep's fast path reads them)
     A(hipMalloc(&q.amax, 256));
     if (rc != FIC_OK) {
         void* ptrs[] = {q.poolQ, q.dflat, q.rngQ, q.qst, q.rngE, q.theta_g, q.amax};

@@ -90,7 +90,7 @@ struct fic_ctx {
     hipStream_t last_stream = nullptr;
     hipStream_t own_stream = nullptr; // non-blocking stream of the multi-device entry (created on demand)
     int opt_sweep = 0, opt_chunks = 0, opt_time = 0, opt_noflag = 0;
-    int last_chunks = 0, last_kind = 0, last_fused = 0;
+    int last_chunks = 0, last_kind = 0, last_fused = 0, last_tiles_per_chunk = 0;
     std::vector<hipEvent_t> ev;      // pairs start/stop
     double acc_ms = 0.0;
     int acc_n = 0;

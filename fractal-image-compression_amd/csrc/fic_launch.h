@@ -157,7 +157,8 @@ int fic_launch_sweep_d4(const FicBuffers& b, const uint32_t* rng_d4, const uint3
 int fic_q_ct(int B);                 // column tiles (x32 columns) per workgroup
 int fic_q_ctw_host(int B);           // column tiles (x32 columns) one wave keeps in registers
 int fic_q_prep_fused(const FicGeom& g, int ndtiles_alloc, int ngrp);   // 1: fic_launch_q_prep makes the scaled image itself (no k_scale before it)
-int fic_q_shape16(const FicGeom& g); // 1: k_sweep_q16 (v_mfma_f32_16x16x32_f16) runs this geometry's 1-isometry sweep
+int fic_q_shape16(const FicGeom& g);
+int fic_q_multi_kind(int nchunks, int tiles_per_chunk);   // 0: k_sweep_q<.., false>, 1: <.., true>, 2: k_sweep_qs / k_sweep_q16s (short chunks) // 1: k_sweep_q16 (v_mfma_f32_16x16x32_f16) runs this geometry's 1-isometry sweep
 int fic_q_cols_per_range(int B, int n_iso);   // sweep columns per range block: 1 (1 isometry), 8 (B = 4), 4 (isometry pairs, B = 8 / 16)
 int fic_q_unroll(int B, int n_iso);   // unroll factor of the sweep loop: chunks are whole multiples, the store has that many spare tiles twice
 int fic_q_resident(int B);          // workgroups of k_sweep_q a CU holds at once (chunk policy)

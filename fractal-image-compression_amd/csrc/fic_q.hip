@@ -88,6 +88,10 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 #define FIC_Q_WAVES_B4 3
 #endif
 __host__ __device__ constexpr int fic_q_ctw(int NK) { return NK == 4 ? FIC_Q_CTW_B8 : (NK < 4 ? FIC_Q_CTW_B4 : 2); }   // column tiles (x32 range copies) per wave
+#define FIC_Q_THG_NONE 0xBF800000u         // theta_g "nothing published": -1.0f; levels are positive floats, so signed-integer order = float order
+#ifndef FIC_Q_GFAST_TILES
+#define FIC_Q_GFAST_TILES 48               // pool chunks of at most this many domain tiles run k_sweep_qs / k_sweep_q16s (theta_g refreshed in the fast path; 0: never, A/B builds)
+#endif
 #ifndef FIC_Q_SEED
 #define FIC_Q_SEED 1                       // pool chunks after the first take their first theta from domain tile 0 (0: A/B builds)
 #endif
@@ -326,7 +330,7 @@ __global__ __launch_bounds__(256) void k_range_q(const uint8_t* __restrict__ gra
                 rng_st[o] = st;
                 rngE[o] = __fadd_rn(__fmul_rn(__fsqrt_rn((float)ss), FIC_Q_ECOEF), FIC_Q_EABS);
                 key[o] = FIC_KEY_NONE;
-                theta_g[o] = 0u;
+                theta_g[o] = FIC_Q_THG_NONE;
             }
         }
     }
@@ -506,7 +510,7 @@ __device__ __forceinline__ void range_q8_body(int grp, int plane, const uint8_t*
                 rng_st[o] = st;
                 rngE[o] = __fadd_rn(__fmul_rn(__fsqrt_rn((float)ss), FIC_Q_ECOEF), FIC_Q_EABS);
                 key[o] = FIC_KEY_NONE;
-                theta_g[o] = 0u;
+                theta_g[o] = FIC_Q_THG_NONE;
             }
         }
     }
@@ -853,8 +857,10 @@ __device__ __forceinline__ void q_finalize_tail(const QArgs& A, int plane, int g
 // -amdgpu-mfma-vgpr-form; with accumulators in AGPRs every element the epilogue tests costs a v_accvgpr_read first).
 // MULTI: the launch has more than one pool chunk (theta_g is shared between the waves of a range); a one-chunk launch is a
 // separate instantiation without any of that code, see (3) in slow_tile.
-template <int NK, int MODE, bool MULTI>
-__global__ __launch_bounds__(64 * FIC_Q_WPG, NK == 4 ? FIC_Q_WAVES_B8 : (NK < 4 ? FIC_Q_WAVES_B4 : 1)) void k_sweep_q(QArgs A)
+// GFAST (k_sweep_qs, short pool chunks): theta_g is refreshed in the fast path (refresh_thg) instead of being loaded in every
+// flagged tile.
+template <int NK, int MODE, bool MULTI, bool GFAST>
+__device__ __forceinline__ void sweep_q_body(const QArgs& A)
 {
     constexpr int CTW = fic_q_ctw(NK), CT = FIC_Q_WPG * CTW;
     constexpr int CSHIFT = QMode<MODE>::CSHIFT;
@@ -902,6 +908,9 @@ __global__ __launch_bounds__(64 * FIC_Q_WPG, NK == 4 ? FIC_Q_WAVES_B8 : (NK < 4 
     }
     // per lane and column tile: the range behind the column, its theta, its error bound
     float tau[CTW], E[CTW], lmn[CTW];                        // lmn: L from which a pair of this range prunes in ANY index order (header)
+    float gl[GFAST ? CTW : 1];                               // MULTI: theta_g of the lane's column per column tile, as last loaded (refresh_thg)
+#pragma unroll
+    for (int ci = 0; ci < (GFAST ? CTW : 1); ci++) gl[ci] = -1.0f;
     uint32_t okbits = 0, raise = 0;                          // bit ci: the column's range exists / may raise theta (rem != 0)
 #pragma unroll
     for (int ci = 0; ci < CTW; ci++) {
@@ -948,11 +957,13 @@ __global__ __launch_bounds__(64 * FIC_Q_WPG, NK == 4 ? FIC_Q_WAVES_B8 : (NK < 4 
         const bool mayraise = (raise >> ci) & 1u;
         const int colw = ci * 32 + jcol;                     // column in wave
         const int jg = ((ctw0 + ci) * 32 + jcol) >> CSHIFT;  // the column's range block (valid when ok)
-        // (3), consumed at the end so that the load overlaps the element loop.  Waiting for it is s_waitcnt vmcnt(0), i.e. also a
-        // wait for the prefetched domain fragments (an L2 round trip per flagged tile): the one-chunk instantiation -- no other
-        // wave sees this range -- has no vector memory operation in a flagged tile at all.  (A run-time branch instead of a
-        // second instantiation makes the compiler tighten the vmcnt waits of the FAST path: tried, 8 % slower.)
-        const uint32_t g = (MULTI && mayraise) ? thg[jg] : 0u;
+        // (3): a load, waited for at the end of the tile -- a memory round trip, 1.1 us per flagged tile against 0.4 us without
+        // (tools/phases.py; merging it a flagged tile later is no cheaper: the vector-memory counter is in-order, the next wait
+        // for domain fragments waits for it too).  Fine where flagged tiles are rare (long chunks); with short chunks -- one
+        // 512x512 image: 19 of the 46 us a wave spent in its loop -- the GFAST instantiation refreshes theta_g in the fast path
+        // instead (refresh_thg in step(): +3..11 % on long chunks, hence not there).  The one-chunk instantiation -- no other wave
+        // sees this range -- has no vector memory operation in a flagged tile at all.
+        const uint32_t g = (MULTI && !GFAST && mayraise) ? thg[jg] : FIC_Q_THG_NONE;
         const uint32_t ent0 = (uint32_t)(dt * 32 + 4 * half) | ((uint32_t)colw << 24);   // entry of element 0; element e adds its row
         if (first) {                                         // (1)
             const float lo = __fsub_rn(q_share_max<MODE>(ok ? mx : 0.0f), E[ci]);
@@ -989,9 +1000,9 @@ __global__ __launch_bounds__(64 * FIC_Q_WPG, NK == 4 ? FIC_Q_WAVES_B8 : (NK < 4 
         if (mayraise && lo2 >= 0.0f) {
             const float lb = __fsub_rn(__fmul_rn(lo2, FIC_Q_LEVEL), E[ci]);
             tau[ci] = fmaxf(tau[ci], lb);
-            if (MULTI && lo2 >= lmn[ci] && half == 0 && (jcol & ((1 << CSHIFT) - 1)) == 0) atomicMax(&thg[jg], f32_orderable(lb));
+            if (MULTI && lo2 >= lmn[ci] && lb > 0.0f && half == 0 && (jcol & ((1 << CSHIFT) - 1)) == 0) atomicMax((int*)&thg[jg], __float_as_int(lb));
         }
-        if (MULTI && mayraise && g != 0u) tau[ci] = fmaxf(tau[ci], f32_from_orderable(g));
+        if (MULTI && !GFAST && mayraise) tau[ci] = fmaxf(tau[ci], __uint_as_float(g));
         // the fill count after this tile (LDS operations of a wave complete in order); one tile adds at most 1024 entries
         const int tot = __builtin_amdgcn_readfirstlane((int)*(volatile __attribute__((address_space(3))) uint32_t*)(__attribute__((address_space(3))) uint32_t*)myqn);   // ds_read, not a flat load
         st_pairs += (unsigned)(tot - qn);
@@ -1042,7 +1053,20 @@ __global__ __launch_bounds__(64 * FIC_Q_WPG, NK == 4 ? FIC_Q_WAVES_B8 : (NK < 4 
     tile_mfma(a0, rb[0], acc, acc2);
 
     // one domain tile (the fragment store has spare zero tiles behind the pool for the loop's overrun and the prefetch)
-    auto step = [&](int dt, v4i (&ac)[NK], const v4i (&an)[NK], const bool first) __attribute__((always_inline)) {
+    // (3) theta_g, the best level any wave has published for the lane's ranges (other pool chunks): every step merges the levels of
+    // half of the column tiles -- loaded two steps ago, next to the fragment loads, so nobody waits for them -- and requests
+    // them again: a load and a v_max per column tile and two domain tiles.  PH = which half (the loop alternates two steps).
+    auto refresh_thg = [&](auto ph) __attribute__((always_inline)) {
+        if constexpr (MULTI && GFAST) {
+            constexpr int PH = decltype(ph)::value, H = CTW / 2;
+#pragma unroll
+            for (int c = PH * H; c < PH * H + H; c++) {
+                tau[c] = fmaxf(tau[c], gl[c]);               // (columns that never raise hold TAU_ALL; "nothing published" is -1)
+                gl[c] = __uint_as_float(thg[((ctw0 + c) * 32 + jcol) >> CSHIFT]);
+            }
+        }
+    };
+    auto step = [&](int dt, v4i (&ac)[NK], const v4i (&an)[NK], const bool first, auto ph) __attribute__((always_inline)) {
 #pragma unroll
         for (int ci = 0; ci < CTW; ci++) {
             // the next tile's MFMAs: column tile ci+1 of this domain tile, or column tile 0 of the next domain tile
@@ -1052,6 +1076,7 @@ __global__ __launch_bounds__(64 * FIC_Q_WPG, NK == 4 ? FIC_Q_WAVES_B8 : (NK < 4 
             if (ci == CTW - 2) {
 #pragma unroll
                 for (int m = 0; m < NK; m++) ac[m] = pa[((size_t)(dt + 2) * NK + m) * 64];
+                refresh_thg(ph);
             }
             const float mx = FOLD ? max16_sum(acc, acc2) : max16_abs(acc);
             const bool hit = mx > tau[ci];
@@ -1095,11 +1120,31 @@ __global__ __launch_bounds__(64 * FIC_Q_WPG, NK == 4 ? FIC_Q_WAVES_B8 : (NK < 4 
             if constexpr (FOLD) acc2 = nacc2;
         }
     };
+#ifdef FIC_Q_PHASES
+    const unsigned long long ph1 = clock64();
+#endif
     for (int dt = dt0; dt < dt1; dt += 2) {
-        step(dt, a0, a1, dt == dt0);                         // first: a chunk's first tile (theta is seeded there)
-        step(dt + 1, a1, a0, false);
+        step(dt, a0, a1, dt == dt0, std::integral_constant<int, 0>());     // first: a chunk's first tile (theta is seeded there)
+        step(dt + 1, a1, a0, false, std::integral_constant<int, 1>());
     }
+#ifdef FIC_Q_PHASES
+    const unsigned long long ph2 = clock64();
+#endif
     flush();
+#ifdef FIC_Q_PHASES
+    // diagnostic build: the sampled waves report where their cycles went -- prologue | loop | final flush; [3] = loop cycles of the first step pair
+    if (A.stats && lane == 0 && (blockIdx.x & 15) == 0 && wave == 0) {
+        atomicAdd(&A.stats[0], ph1 - clk0);
+        atomicAdd(&A.stats[1], ph2 - ph1);
+        atomicAdd(&A.stats[2], (unsigned long long)clock64() - ph2);
+        atomicAdd(&A.stats[4], (unsigned long long)(clock64() - clk0));
+        atomicAdd(&A.stats[5], (unsigned long long)(wall_clock64() - tick0));
+        atomicAdd(&A.stats[6], 1ull);
+        atomicAdd(&A.stats[3], (unsigned long long)st_slow);
+        atomicAdd(&A.stats[7], (unsigned long long)st_pairs);
+    }
+    if (false)
+#endif
     if (A.stats && lane == 0) {
         atomicAdd(&A.stats[0], (unsigned long long)(dt1 - dt0) * (unsigned)nci);
         atomicAdd(&A.stats[1], (unsigned long long)st_slow);
@@ -1146,8 +1191,8 @@ __device__ __forceinline__ float q16_share_max(float v)
     const auto q = __builtin_amdgcn_permlane32_swap(uw, uw, false, false);    // the two halves
     return fmaxf(__uint_as_float(q[0]), __uint_as_float(q[1]));
 }
-template <int NK, bool MULTI>
-__global__ __launch_bounds__(64 * FIC_Q_WPG, NK == 4 ? FIC_Q_WAVES_B8 : 1) void k_sweep_q16(QArgs A)
+template <int NK, bool MULTI, bool GFAST>
+__device__ __forceinline__ void sweep_q16_body(const QArgs& A)
 {
     constexpr int CTW = fic_q_ctw(NK), CT = FIC_Q_WPG * CTW, CU = 2 * CTW, KS = NK / 2;
     __shared__ uint32_t sQ[FIC_Q_WPG][FIC_Q_QCAP + 4];         // per wave: domain block | column-in-wave << 24; [QCAP] = fill count
@@ -1191,6 +1236,9 @@ __global__ __launch_bounds__(64 * FIC_Q_WPG, NK == 4 ? FIC_Q_WAVES_B8 : 1) void 
             for (int m = 0; m < NK; m++) rb[ci][m] = rp[(ci * NK + m) * 64];
     }
     float tau[CU], E[CU], lmn[CU];
+    float gl[GFAST ? CU : 1];
+#pragma unroll
+    for (int cj = 0; cj < (GFAST ? CU : 1); cj++) gl[cj] = -1.0f;
     uint32_t okbits = 0, raise = 0;
 #pragma unroll
     for (int cj = 0; cj < CU; cj++) {
@@ -1225,7 +1273,7 @@ __global__ __launch_bounds__(64 * FIC_Q_WPG, NK == 4 ? FIC_Q_WAVES_B8 : 1) void 
         const bool mayraise = (raise >> cj) & 1u;
         const int colw = cj * 16 + c16;                      // column in wave
         const int jg = ctw0 * 32 + colw;                     // the column's range block (valid when ok)
-        const uint32_t g = (MULTI && mayraise) ? thg[jg] : 0u;
+        const uint32_t g = (MULTI && !GFAST && mayraise) ? thg[jg] : FIC_Q_THG_NONE;    // (3); GFAST: in the fast path (refresh_thg)
         const uint32_t ent0 = (uint32_t)(dt * 32 + 4 * g4) | ((uint32_t)colw << 24);     // entry of element 0; element e adds 16 (e >> 2) + (e & 3)
         if (first) {                                         // (1) out-of-order seed, only from a pair with L >= lmn
             const float lo = __fsub_rn(q16_share_max(ok ? mx : 0.0f), E[cj]);
@@ -1255,9 +1303,9 @@ __global__ __launch_bounds__(64 * FIC_Q_WPG, NK == 4 ? FIC_Q_WAVES_B8 : 1) void 
         if (mayraise && lo2 >= 0.0f) {
             const float lb = __fsub_rn(__fmul_rn(lo2, FIC_Q_LEVEL), E[cj]);
             tau[cj] = fmaxf(tau[cj], lb);
-            if (MULTI && lo2 >= lmn[cj] && g4 == 0) atomicMax(&thg[jg], f32_orderable(lb));
+            if (MULTI && lo2 >= lmn[cj] && lb > 0.0f && g4 == 0) atomicMax((int*)&thg[jg], __float_as_int(lb));
         }
-        if (MULTI && mayraise && g != 0u) tau[cj] = fmaxf(tau[cj], f32_from_orderable(g));           // (3)
+        if (MULTI && !GFAST && mayraise) tau[cj] = fmaxf(tau[cj], __uint_as_float(g));       // (3)
         const int tot = __builtin_amdgcn_readfirstlane((int)*(volatile __attribute__((address_space(3))) uint32_t*)(__attribute__((address_space(3))) uint32_t*)myqn);
         st_pairs += (unsigned)(tot - qn);
         qn = tot;
@@ -1294,7 +1342,17 @@ __global__ __launch_bounds__(64 * FIC_Q_WPG, NK == 4 ? FIC_Q_WAVES_B8 : 1) void 
 #pragma unroll
     for (int m = 0; m < NK; m++) a1[m] = pa[((size_t)(dt0 + 1) * NK + m) * 64];
     unit_mfma(a0, 0, x0, x1);
-    auto step = [&](int dt, v4i (&ac)[NK], const v4i (&an)[NK], const bool first) __attribute__((always_inline)) {
+    auto refresh_thg = [&](auto ph) __attribute__((always_inline)) {      // as in k_sweep_q: half of the units per step
+        if constexpr (MULTI && GFAST) {
+            constexpr int PH = decltype(ph)::value, H = CU / 2;
+#pragma unroll
+            for (int c = PH * H; c < PH * H + H; c++) {
+                tau[c] = fmaxf(tau[c], gl[c]);
+                gl[c] = __uint_as_float(thg[ctw0 * 32 + c * 16 + c16]);
+            }
+        }
+    };
+    auto step = [&](int dt, v4i (&ac)[NK], const v4i (&an)[NK], const bool first, auto ph) __attribute__((always_inline)) {
 #pragma unroll
         for (int cj = 0; cj < CU; cj++) {
             v4f n0, n1;
@@ -1303,6 +1361,7 @@ __global__ __launch_bounds__(64 * FIC_Q_WPG, NK == 4 ? FIC_Q_WAVES_B8 : 1) void 
             if (cj == CU - 2) {
 #pragma unroll
                 for (int m = 0; m < NK; m++) ac[m] = pa[((size_t)(dt + 2) * NK + m) * 64];
+                refresh_thg(ph);
             }
             const float mx = max8_abs(x0, x1);
             const bool hit = mx > tau[cj];
@@ -1312,8 +1371,8 @@ __global__ __launch_bounds__(64 * FIC_Q_WPG, NK == 4 ? FIC_Q_WAVES_B8 : 1) void 
         }
     };
     for (int dt = dt0; dt < dt1; dt += 2) {
-        step(dt, a0, a1, dt == dt0);
-        step(dt + 1, a1, a0, false);
+        step(dt, a0, a1, dt == dt0, std::integral_constant<int, 0>());
+        step(dt + 1, a1, a0, false, std::integral_constant<int, 1>());
     }
     flush();
     if (A.stats && lane == 0) {
@@ -1330,23 +1389,50 @@ __global__ __launch_bounds__(64 * FIC_Q_WPG, NK == 4 ? FIC_Q_WAVES_B8 : 1) void 
     if (A.fin_count) q_finalize_tail<NK, 0>(A, plane, gx_, &s_wdone, lane);
 }
 
+// The kernels: one pool chunk / several (theta_g shared between the waves of a range) / several SHORT ones (k_sweep_qs).
+template <int NK, int MODE, bool MULTI>
+__global__ __launch_bounds__(64 * FIC_Q_WPG, NK == 4 ? FIC_Q_WAVES_B8 : (NK < 4 ? FIC_Q_WAVES_B4 : 1)) void k_sweep_q(QArgs A)
+{
+    sweep_q_body<NK, MODE, MULTI, false>(A);
+}
+template <int NK, int MODE>
+__global__ __launch_bounds__(64 * FIC_Q_WPG, NK == 4 ? FIC_Q_WAVES_B8 : (NK < 4 ? FIC_Q_WAVES_B4 : 1)) void k_sweep_qs(QArgs A)
+{
+    sweep_q_body<NK, MODE, true, true>(A);
+}
+template <int NK, bool MULTI>
+__global__ __launch_bounds__(64 * FIC_Q_WPG, NK == 4 ? FIC_Q_WAVES_B8 : 1) void k_sweep_q16(QArgs A)
+{
+    sweep_q16_body<NK, MULTI, false>(A);
+}
+template <int NK>
+__global__ __launch_bounds__(64 * FIC_Q_WPG, NK == 4 ? FIC_Q_WAVES_B8 : 1) void k_sweep_q16s(QArgs A)
+{
+    sweep_q16_body<NK, true, true>(A);
+}
+
 // ---------------------------------------------------------------------------------------------
 // host-side launchers
 // ---------------------------------------------------------------------------------------------
+// multi: 0 = one pool chunk, 1 = several, 2 = several short ones (fic_q_multi_kind)
 template <int NK, int MODE>
-static void q_launch_nm(bool multi, dim3 grid, dim3 block, hipStream_t s, const QArgs& A)
+static void q_launch_nm(int multi, dim3 grid, dim3 block, hipStream_t s, const QArgs& A)
 {
-    if (multi) hipLaunchKernelGGL((k_sweep_q<NK, MODE, true>), grid, block, 0, s, A);
+    if (multi == 2) hipLaunchKernelGGL((k_sweep_qs<NK, MODE>), grid, block, 0, s, A);
+    else if (multi) hipLaunchKernelGGL((k_sweep_q<NK, MODE, true>), grid, block, 0, s, A);
     else hipLaunchKernelGGL((k_sweep_q<NK, MODE, false>), grid, block, 0, s, A);
 }
+int fic_q_multi_kind(int nchunks, int tiles_per_chunk) { return nchunks <= 1 ? 0 : (tiles_per_chunk <= FIC_Q_GFAST_TILES ? 2 : 1); }
 // NK = n / 16; mode 0 / 1 / 2 as fic_q_mode, 3 = joint RGB.  false: no such kernel
-static bool q_launch(int NK, int mode, bool multi, dim3 grid, dim3 block, hipStream_t s, const QArgs& A, int shape16 = 0)
+static bool q_launch(int NK, int mode, int multi, dim3 grid, dim3 block, hipStream_t s, const QArgs& A, int shape16 = 0)
 {
     if (shape16 && mode == 0 && NK == 4) {
-        if (multi) hipLaunchKernelGGL((k_sweep_q16<4, true>), grid, block, 0, s, A);
+        if (multi == 2) hipLaunchKernelGGL((k_sweep_q16s<4>), grid, block, 0, s, A);
+        else if (multi) hipLaunchKernelGGL((k_sweep_q16<4, true>), grid, block, 0, s, A);
         else hipLaunchKernelGGL((k_sweep_q16<4, false>), grid, block, 0, s, A);
     } else if (shape16 && mode == 0 && NK == 16) {
-        if (multi) hipLaunchKernelGGL((k_sweep_q16<16, true>), grid, block, 0, s, A);
+        if (multi == 2) hipLaunchKernelGGL((k_sweep_q16s<16>), grid, block, 0, s, A);
+        else if (multi) hipLaunchKernelGGL((k_sweep_q16<16, true>), grid, block, 0, s, A);
         else hipLaunchKernelGGL((k_sweep_q16<16, false>), grid, block, 0, s, A);
     } else if (NK == 1 && mode == 0) q_launch_nm<1, 0>(multi, grid, block, s, A);
     else if (NK == 1 && mode == 1) q_launch_nm<1, 1>(multi, grid, block, s, A);
@@ -1450,7 +1536,7 @@ int fic_launch_sweep_q(const FicBuffers& b, const void* poolQ, const void* dflat
         return (int)hipErrorInvalidValue;
     dim3 grid((unsigned)(nchunks * g.planes) * (unsigned)A.nctg), block(64 * FIC_Q_WPG);
     const int mode = fic_q_mode(g.B, g.n_iso);
-    if (!q_launch(g.B * g.B / 16, mode, nchunks > 1, grid, block, s, A, fic_q_shape16(g))) return (int)hipErrorInvalidValue;
+    if (!q_launch(g.B * g.B / 16, mode, fic_q_multi_kind(nchunks, tiles_per_chunk), grid, block, s, A, fic_q_shape16(g))) return (int)hipErrorInvalidValue;
     FIC_LAUNCH_CHECK();
     return 0;
 }
@@ -1546,7 +1632,7 @@ __global__ __launch_bounds__(256) void k_range_qrgb(const int16_t* __restrict__ 
             rngE[j] = __fadd_rn(__fmul_rn(__fmul_rn(__fmul_rn(__fsqrt_rn((float)s2), 1.0001f), am), FIC_Q_ECOEF),
                                 __fmul_rn(FIC_Q_EABS, __fadd_rn(1.0f, am)));
             key[j] = FIC_KEY_NONE;
-            theta_g[j] = 0u;
+            theta_g[j] = FIC_Q_THG_NONE;
         }
     }
     for (int t = threadIdx.x; t < 2 * NK * 64; t += 256) {
@@ -1594,7 +1680,7 @@ int fic_launch_rgbq(const uint16_t* pool_sum, const FicRgbDomStat* pool_st, cons
     if (A.nctg * CT > nct_alloc || (nct_alloc & 1) || g.Nd >= (1 << 24) || A.ndtiles_loop + unroll > ndtiles_alloc || tiles_per_chunk % unroll)
         return (int)hipErrorInvalidValue;
     dim3 grid((unsigned)nchunks * (unsigned)A.nctg), block(64 * FIC_Q_WPG);
-    if (!q_launch(g.B * g.B / 16, 3, nchunks > 1, grid, block, s, A)) return (int)hipErrorInvalidValue;
+    if (!q_launch(g.B * g.B / 16, 3, fic_q_multi_kind(nchunks, tiles_per_chunk), grid, block, s, A)) return (int)hipErrorInvalidValue;
     FIC_LAUNCH_CHECK();
     return 0;
 }

@@ -174,10 +174,10 @@ def test_q16_sweep_matches_oracle(oracle, name, B):
     ref = _ref(oracle, name, B, 1)
     for chunks in (0, 1, 3, 50, 10000):
         got, kname = _encode_shape(g, B, 1, chunks)
-        assert kname.startswith(f"k_sweep_q16<{B * B // 16}, "), kname
+        assert kname.startswith((f"k_sweep_q16<{B * B // 16}, ", f"k_sweep_q16s<{B * B // 16}>")), kname     # (k_sweep_q16s: short pool chunks)
         _check(oracle, got, ref)
     got, kname = _encode_shape(g, B, 2)
-    assert kname.startswith(f"k_sweep_q<{B * B // 16}, 0, "), kname
+    assert kname.startswith((f"k_sweep_q<{B * B // 16}, 0, ", f"k_sweep_qs<{B * B // 16}, 0>")), kname
     _check(oracle, got, ref)
 
 
@@ -188,11 +188,11 @@ def test_q16_is_chosen_by_pool_size_and_batches_and_shards():
     with fic_amd.Encoder(256, 256, 8, None, 1, planes=3) as enc:
         enc.set_gray(imgs)
         enc.encode()
-        assert enc.last_kernel().startswith("k_sweep_q<4, 0, ")
+        assert enc.last_kernel().startswith(("k_sweep_q<4, 0, ", "k_sweep_qs<4, 0>"))
         whole = {k: v.copy() for k, v in enc.results().items()}
         enc.set_option("q_shape", 1)
         enc.encode()
-        assert enc.last_kernel().startswith("k_sweep_q16<4, ")
+        assert enc.last_kernel().startswith(("k_sweep_q16<4, ", "k_sweep_q16s<4>"))
         forced = {k: v.copy() for k, v in enc.results().items()}
         parts = []
         for b, c in fic_amd.shard_spans(enc.n_ranges, enc.ranges_per_tile, 3):
@@ -221,6 +221,7 @@ def test_small_launches_run_as_two_kernels(oracle):
         want = fic_amd.encode_gray(g, 8, None, n_iso, sweep=2)
         with fic_amd.Encoder(512, 512, 8, None, n_iso) as enc:
             enc.set_gray(g)
+            seen = set()
             for chunks, shape in ((0, 0), (0, 0), (1, 0), (7, 0), (500, 0), (0, 1), (3, 1), (0, 0)):
                 if n_iso == 8 and shape:
                     continue
@@ -228,11 +229,17 @@ def test_small_launches_run_as_two_kernels(oracle):
                 enc.set_option("q_shape", shape)
                 enc.encode()
                 assert enc.last_kernel().endswith(FUSED), enc.last_kernel()
+                seen.add(enc.last_kernel()[:-len(FUSED)])
                 got = {k: v[0] for k, v in enc.results().items()}
                 for k in ("idx_local", "idx_global", "iso", "qrows"):
                     assert (got[k] == want[k]).all(), (n_iso, chunks, shape, k)
                 for k in ("a", "b", "err"):
                     assert same_f32(got[k], want[k]), (n_iso, chunks, shape, k)
+            # one pool chunk, long chunks (theta_g read in flagged tiles), short chunks (k_sweep_qs: theta_g refreshed in the fast path)
+            mode = 2 if n_iso == 8 else 0
+            assert {f"k_sweep_q<4, {mode}, false>", f"k_sweep_q<4, {mode}, true>", f"k_sweep_qs<4, {mode}>"} <= seen, seen
+            if n_iso == 1:
+                assert {"k_sweep_q16s<4>", "k_sweep_q16<4, true>"} <= seen, seen
             enc.set_option("chunks", 0)
             enc.set_option("q_shape", 0)
             # shards: spans of whole range tiles, and one ragged span inside a tile
