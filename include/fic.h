@@ -231,7 +231,8 @@ FIC_API int fic_ctx_sweep_stats(fic_ctx* ctx, uint64_t* out8, int reset);
 /* Geometry actually in use: out[0..9] = Rw, Rh, N_r, Dw, Dh, N_d, NR, tiles, chunks, sweep kind. */
 FIC_API int fic_ctx_info(fic_ctx* ctx, int* out10);
 /* Name of the sweep kernel the context's last encode launched (as rocprofv3 prints it, without the argument list), e.g.
- * "k_sweep_q<4, 2, false>" or "k_sweep_q16<4, true>" -- so that a caller can match its timing with a profile.  A small launch
+ * "k_sweep_q<4, 2, false>" (one pool chunk), "k_sweep_q16<4, true>" (several) or "k_sweep_qs<4, 2>" / "k_sweep_q16s<4>" (several short
+ * ones: theta is shared between the chunks in the fast path) -- so that a caller can match its timing with a profile.  A small launch
  * of the default sweep (one image up to about 512x512 at B = 8) runs as two kernels instead of five -- k_prep_q8 (scale + pool +
  * range prep) and the sweep, whose last workgroup per range-column group also does k_finalize's work -- and the name then
  * carries the suffix " after k_prep_q8, finalising". */
