@@ -264,3 +264,54 @@ def test_small_launches_run_as_two_kernels(oracle):
         enc.set_gray(np.stack([IMAGES["lena256"]] * 64))
         enc.encode()
         assert enc.last_kernel() == "k_sweep_q<4, 2, false>" or enc.last_kernel() == "k_sweep_q<4, 2, true>", enc.last_kernel()
+
+
+def test_q16_long_chunks_on_a_batch_of_512_pools():
+    """Round-3 incident (profiles/r03W_*): a build of k_sweep_q16<4, true> (several LONG pool chunks, 16x16x32 MFMA) lost the winners
+    of ~20 % of the range blocks of every wave's third column tile -- only on pools of this size (489 domain tiles in 2-3 chunks),
+    which no test ran through that kernel: the small images of this file give short chunks, the 4096x4096 ones thousands of tiles.
+    40 images through both MFMA shapes with 2 and 3 chunks, separate k_finalize (not a small launch), against the VALU sweep."""
+    P = 40
+    imgs = np.stack([synth.image_u(512, 512, synth.SEEDS["cfg2"] + 3 * p) for p in range(P)])
+    with fic_amd.Encoder(512, 512, 8, None, 1, P) as enc:
+        enc.set_gray(imgs)
+        enc.set_option("sweep", 2)
+        enc.encode()
+        want = {k: v.copy() for k, v in enc.results().items()}
+        enc.set_option("sweep", 6)
+        for chunks, shape, name in ((3, 1, "k_sweep_q16<4, true>"), (2, 1, "k_sweep_q16<4, true>"), (3, 2, "k_sweep_q<4, 0, true>"), (1, 1, "k_sweep_q16<4, false>")):
+            enc.set_option("chunks", chunks)
+            enc.set_option("q_shape", shape)
+            enc.encode()
+            assert enc.last_kernel() == name, enc.last_kernel()
+            got = enc.results()
+            for k in ("idx_local", "idx_global", "iso", "qrows"):
+                bad = np.argwhere(got[k] != want[k])
+                assert bad.size == 0, f"{name} chunks={chunks}: {k}: {len(bad)} mismatches, by column tile in wave {np.bincount((bad[:, 1] % 128) // 32, minlength=4)}"
+            for k in ("a", "b", "err"):
+                assert same_f32(got[k], want[k]), (name, chunks, k)
+
+
+@pytest.mark.parametrize("B,n_iso,size,planes", [(8, 8, 512, 12), (16, 1, 512, 12), (16, 8, 512, 12), (4, 1, 256, 12), (4, 8, 256, 12), (8, 1, 1024, 2)])
+def test_long_chunks_on_medium_pools_every_instantiation(B, n_iso, size, planes):
+    """The same coverage for the other instantiations: pools of a few hundred to a few thousand domain tiles in 2 / 3 / 5 chunks
+    (long chunks: theta_g read in the flagged tiles, prefix seed from tile 0), several planes, both MFMA shapes where there are two,
+    against the VALU sweep."""
+    imgs = np.stack([synth.image_u(size, size, 4000 + 7 * p + B + n_iso) for p in range(planes)])
+    with fic_amd.Encoder(size, size, B, None, n_iso, planes) as enc:
+        enc.set_gray(imgs)
+        enc.set_option("sweep", 2)
+        enc.encode()
+        want = {k: v.copy() for k, v in enc.results().items()}
+        enc.set_option("sweep", 6)
+        for shape in ((1, 2) if (n_iso == 1 and B >= 8) else (0,)):
+            enc.set_option("q_shape", shape)
+            for chunks in (2, 3, 5):
+                enc.set_option("chunks", chunks)
+                enc.encode()
+                got = enc.results()
+                for k in ("idx_local", "idx_global", "iso", "qrows"):
+                    bad = np.argwhere(got[k] != want[k])
+                    assert bad.size == 0, f"{enc.last_kernel()} chunks={chunks}: {k}: {len(bad)} mismatches, first {bad[0]}"
+                for k in ("a", "b", "err"):
+                    assert same_f32(got[k], want[k]), (enc.last_kernel(), chunks, k)
