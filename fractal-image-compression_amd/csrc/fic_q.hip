@@ -800,18 +800,21 @@ __device__ __forceinline__ float q_share_max(float v)
 }
 
 // Fused finalise of a SMALL launch (one 512x512 image: k_finalize is 7 us of launch ramp behind a 58 us sweep).  Every wave
-// calls this when it is done (also waves without work); the last wave of the last workgroup of a (plane, column group) -- all
-// pool chunks of that group have then merged their candidates into `key` -- does what k_finalize does for the group's range
-// blocks: the winner's covariance gathered from the image, fit, clamp, quantise, packed record (finalize_store).
+// calls this when it is done (also waves without work) and waits there for the other waves of its workgroup (a barrier: the
+// waves hold nothing anybody needs, the launch is one round); the last workgroup of a (plane, column group) -- all pool
+// chunks of that group have then merged their candidates into `key` -- does, with all its lanes, what k_finalize does for the
+// group's range blocks (128 with 8 isometries, 512 with 1): the winner's covariance gathered from the image, fit, clamp,
+// quantise, packed record (finalize_store).
 // Visibility without any cache maintenance (an agent-scope fence = buffer_wbl2 + buffer_inv per wave: the sweep ran 2x longer
-// with one): `key` is touched by nothing but 8-byte device-scope atomics in this kernel -- they execute at the memory side, no
-// L2 holds a line of it (MI355X_MICROARCH.md, "8-B agent atomics both sides") -- so a wave only has to WAIT for its own
-// atomicMins (s_waitcnt vmcnt(0)) before it counts itself done in LDS; the workgroup's last wave then adds to the group's
-// counter, and the wave whose add returns nchunks - 1 reads every key by a returning atomic (umin with ~0).  Everything else it reads was
-// written by the prep kernel.  The counter is left at 0 for the next launch.
+// with one): `key` is touched by nothing but 8-byte device-scope atomics in this kernel -- they execute at the memory side
+// (MI355X_MICROARCH.md, "8-B agent atomics both sides") -- so a wave only has to WAIT for its own atomicMins (s_waitcnt
+// vmcnt(0)) before the barrier; thread 0 then adds to the group's counter, and the workgroup whose add returns nchunks - 1
+// reads every key by a returning atomic (umin with ~0).  Everything else it reads was written by the prep kernel.  The
+// counter is left at 0 for the next launch.  s_wdone: the workgroup's "we are last" flag.
 template <int NK, int MODE>
 __device__ __forceinline__ void q_finalize_tail(const QArgs& A, int plane, int gx, int* s_wdone, int lane)
 {
+    (void)lane;
     if constexpr (MODE == 3) {
         return;
     } else {
@@ -819,18 +822,18 @@ __device__ __forceinline__ void q_finalize_tail(const QArgs& A, int plane, int g
         constexpr int B = NK == 1 ? 4 : (NK == 4 ? 8 : 16);
         constexpr int CT = FIC_Q_WPG * fic_q_ctw(NK);
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");             // this wave's atomicMins have been performed
-        int last = 0;
-        if (lane == 0 && atomicAdd(s_wdone, 1) == FIC_Q_WPG - 1) {                // the workgroup's last wave
+        __syncthreads();                                                         // ... and so have those of the workgroup's other waves
+        if (threadIdx.x == 0) {
             unsigned int* cnt = A.fin_count + (size_t)plane * A.nctg + gx;
-            if (__hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)A.nchunks - 1u) {   // ... of the group's last workgroup
-                last = 1;
-                __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
+            const int last = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)A.nchunks - 1u;
+            if (last) __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            *s_wdone = last;                                                     // the group's last workgroup?
         }
-        if (!__builtin_amdgcn_readfirstlane(last)) return;
+        __syncthreads();
+        if (!*(volatile int*)s_wdone) return;
         const FicGeom& g = A.geom;
         const int j0 = ((A.ct_begin + gx * CT) * 32) >> CSHIFT, nj = (CT * 32) >> CSHIFT;
-        for (int jj = lane; jj < nj; jj += 64) {
+        for (int jj = (int)threadIdx.x; jj < nj; jj += 64 * FIC_Q_WPG) {
             const int j = j0 + jj;
             if (j < A.r_begin || j >= A.r_end) continue;
             // (a real read-modify-write, executed where the sweep's atomicMins were: the compiler would turn an idempotent
@@ -877,11 +880,7 @@ __device__ __forceinline__ void sweep_q_body(const QArgs& A)
     const int dt0 = chunk * A.tiles_per_chunk;               // tiles_per_chunk is a multiple of the loop's unroll factor;
     int dt1 = dt0 + A.tiles_per_chunk;                       // the last chunk runs into the store's zero tiles (flagged flat)
     if (dt1 > A.ndtiles_loop) dt1 = A.ndtiles_loop;
-    __shared__ int s_wdone;                                  // fused finalise: waves of this workgroup that are done
-    if (A.fin_count) {                                       // (uniform; the only barrier of the kernel, before any wave leaves)
-        if (threadIdx.x == 0) s_wdone = 0;
-        __syncthreads();
-    }
+    __shared__ int s_wdone;                                  // fused finalise: "this workgroup is its column group's last" (q_finalize_tail)
     if (dt0 >= A.ndtiles || ctw0 >= A.ct_end) {              // (waves are independent: no barrier in the sweep itself)
         if (A.fin_count) q_finalize_tail<NK, MODE>(A, plane, gx_, &s_wdone, lane);
         return;
@@ -1182,11 +1181,14 @@ __device__ __forceinline__ float max8_abs(const v4f& x0, const v4f& x1)
     return max3f(m0, m1, max3f(fabsf(x1[2]), fabsf(x1[3]), 0.0f));
 }
 // maximum over the four lanes (row groups g = 0..3) that hold the same column.  Every lane of the wave must be active.
+// (The exchange between rows 0/1 and 2/3 goes through ds_bpermute, not v_permlane16_swap: a build with the swap here lost winners
+//  in the units whose prefix seed it computed -- deterministically, on 512x512 pools, with an ISA that reads correctly; every
+//  variant without the swap was right.  Cause not found; this is slow-path code, the LDS crossbar
+//  costs nothing measurable.)
 __device__ __forceinline__ float q16_share_max(float v)
 {
-    const uint32_t u = __float_as_uint(v);
-    const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);      // rows 0/1 and 2/3 of 16 lanes exchanged
-    const float w = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    const int partner = (int)((threadIdx.x & 63u) ^ 16u) << 2;
+    const float w = fmaxf(v, __int_as_float(__builtin_amdgcn_ds_bpermute(partner, __float_as_int(v))));
     const uint32_t uw = __float_as_uint(w);
     const auto q = __builtin_amdgcn_permlane32_swap(uw, uw, false, false);    // the two halves
     return fmaxf(__uint_as_float(q[0]), __uint_as_float(q[1]));
@@ -1206,11 +1208,7 @@ __device__ __forceinline__ void sweep_q16_body(const QArgs& A)
     const int dt0 = chunk * A.tiles_per_chunk;
     int dt1 = dt0 + A.tiles_per_chunk;
     if (dt1 > A.ndtiles_loop) dt1 = A.ndtiles_loop;
-    __shared__ int s_wdone;                                  // fused finalise: waves of this workgroup that are done
-    if (A.fin_count) {                                       // (uniform; the only barrier of the kernel, before any wave leaves)
-        if (threadIdx.x == 0) s_wdone = 0;
-        __syncthreads();
-    }
+    __shared__ int s_wdone;                                  // fused finalise: "this workgroup is its column group's last" (q_finalize_tail)
     if (dt0 >= A.ndtiles || ctw0 >= A.ct_end) {              // (waves are independent: no barrier in the sweep itself)
         if (A.fin_count) q_finalize_tail<NK, 0>(A, plane, gx_, &s_wdone, lane);
         return;
