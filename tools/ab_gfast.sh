@@ -1,4 +1,5 @@
-# same-box A/B: k_sweep_qs (theta_g refreshed in the fast path of short pool chunks) against a build without it (-DFIC_Q_GFAST_TILES=0)
+# same-box A/B: k_sweep_qs (theta_g refreshed in the fast path of short pool chunks) against a build without it.  Build the variant first:
+#   cd fractal-image-compression_amd && FIC_HIPCC_FLAGS=-DFIC_Q_GFAST_TILES=0 python build.py && cp libfic_hip.so ../libfic_nogfast_ab.so && python build.py
 cd $GRAFT_REPO_ROOT
 for r in 1 2; do
 for so in libfic_nogfast_ab.so ""; do

@@ -1,3 +1,5 @@
+# same-box A/B of the prefix seed: the default library against a build without it.  Build the variant first (in the container):
+#   cd fractal-image-compression_amd && FIC_HIPCC_FLAGS=-DFIC_Q_SEED=0 python build.py && cp libfic_hip.so ../libfic_noseed_ab.so && python build.py
 cd $GRAFT_REPO_ROOT
 for r in 1 2; do
 for so in "" libfic_noseed_ab.so; do
