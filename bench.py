@@ -776,6 +776,11 @@ def main():
         ni["verified"] = bool(all((a_[k].view(np.uint32) == b_[k].view(np.uint32)).all() if a_[k].dtype == np.float32 else (a_[k] == b_[k]).all()
                                   for k in ("idx_local", "iso", "qrows", "a", "b", "err")))
         out["single_image"]["natural_image"] = ni
+        if n_iso != 1:          # the reference algorithm (no isometries) on the same image
+            watchdog.stage = "single_image_one_isometry"
+            oi = single_image(fic_amd, torch, run.make_image(run.seed), B, 1, local_rank, args.sweep, reps=100)
+            oi["workload"] = oi["workload"].replace("(BASELINE config 2 literally)", "(config 2's image through the reference algorithm: 1 isometry)")
+            out["single_image"]["one_isometry"] = oi
     img0 = run.dev_in[0].cpu().numpy() if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None
     run.close()
 
