@@ -785,7 +785,11 @@ __device__ __forceinline__ void q_flush(const QArgs& A, const uint32_t* myq, int
 
 // maximum over the lanes that share a range block: the two lane halves (rows 0-31 / 32-63 of the same column) and the
 // range's 2^CSHIFT adjacent columns.  Every lane of the wave must be active.
-template <int MODE>
+// SEED: the prefix seed's CTW back-to-back shares exchange the lane halves through ds_bpermute instead of v_permlane32_swap --
+// k_sweep_q16's seed lost winners with the sibling instruction v_permlane16_swap in exactly that position (DESIGN.md section 7,
+// item 6; cause not found), and the seed runs once per pool chunk: the LDS crossbar costs nothing there.  Flagged tiles keep
+// the swap (one share per tile, on the sweep's critical path, never seen to fail).
+template <int MODE, bool SEED = false>
 __device__ __forceinline__ float q_share_max(float v)
 {
     if constexpr (QMode<MODE>::CSHIFT >= 2) {
@@ -794,9 +798,14 @@ __device__ __forceinline__ float q_share_max(float v)
     }
     if constexpr (QMode<MODE>::CSHIFT == 3)
         v = fmaxf(v, __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), 0x141, 0xF, 0xF, true)));  // row_half_mirror
-    const uint32_t u = __float_as_uint(v);
-    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);      // {lanes 0-31 twice, lanes 32-63 twice}
-    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    if constexpr (SEED) {
+        const int partner = (int)((threadIdx.x & 63u) ^ 32u) << 2;
+        return fmaxf(v, __int_as_float(__builtin_amdgcn_ds_bpermute(partner, __float_as_int(v))));
+    } else {
+        const uint32_t u = __float_as_uint(v);
+        const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);  // {lanes 0-31 twice, lanes 32-63 twice}
+        return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    }
 }
 
 // Fused finalise of a SMALL launch (one 512x512 image: k_finalize is 7 us of launch ramp behind a 58 us sweep).  Every wave
@@ -1040,7 +1049,7 @@ __device__ __forceinline__ void sweep_q_body(const QArgs& A)
                 tile_mfma(a0, rb[ci], acc, acc2);
                 const float mx = FOLD ? max16_sum(acc, acc2) : max16_abs(acc);
                 const bool ok = (okbits >> ci) & 1u, mayraise = (raise >> ci) & 1u;
-                const float lo = __fsub_rn(q_share_max<MODE>(ok ? mx : 0.0f), E[ci]);
+                const float lo = __fsub_rn(q_share_max<MODE, true>(ok ? mx : 0.0f), E[ci]);
                 if (mayraise && lo > 0.0f) tau[ci] = fmaxf(tau[ci], __fsub_rn(__fmul_rn(lo, FIC_Q_LEVEL), E[ci]));
             }
         }
@@ -1185,10 +1194,12 @@ __device__ __forceinline__ float max8_abs(const v4f& x0, const v4f& x1)
 //  in the units whose prefix seed it computed -- deterministically, on 512x512 pools, with an ISA that reads correctly; every
 //  variant without the swap was right.  Cause not found; this is slow-path code, the LDS crossbar
 //  costs nothing measurable.)
+template <bool SEED = false>
 __device__ __forceinline__ float q16_share_max(float v)
 {
     const int partner = (int)((threadIdx.x & 63u) ^ 16u) << 2;
     const float w = fmaxf(v, __int_as_float(__builtin_amdgcn_ds_bpermute(partner, __float_as_int(v))));
+    if constexpr (SEED) return fmaxf(w, __int_as_float(__builtin_amdgcn_ds_bpermute((int)((threadIdx.x & 63u) ^ 32u) << 2, __float_as_int(w))));
     const uint32_t uw = __float_as_uint(w);
     const auto q = __builtin_amdgcn_permlane32_swap(uw, uw, false, false);    // the two halves
     return fmaxf(__uint_as_float(q[0]), __uint_as_float(q[1]));
@@ -1274,7 +1285,7 @@ __device__ __forceinline__ void sweep_q16_body(const QArgs& A)
         const uint32_t g = (MULTI && !GFAST && mayraise) ? thg[jg] : FIC_Q_THG_NONE;    // (3); GFAST: in the fast path (refresh_thg)
         const uint32_t ent0 = (uint32_t)(dt * 32 + 4 * g4) | ((uint32_t)colw << 24);     // entry of element 0; element e adds 16 (e >> 2) + (e & 3)
         if (first) {                                         // (1) out-of-order seed, only from a pair with L >= lmn
-            const float lo = __fsub_rn(q16_share_max(ok ? mx : 0.0f), E[cj]);
+            const float lo = __fsub_rn(q16_share_max<>(ok ? mx : 0.0f), E[cj]);
             if (mayraise && lo >= lmn[cj]) tau[cj] = fmaxf(tau[cj], __fsub_rn(__fmul_rn(lo, FIC_Q_LEVEL), E[cj]));
         }
         const bool cand0 = first && dt == 0 && g4 == 0 && ok;                // candidate 0 = block 0: always evaluated
@@ -1297,7 +1308,7 @@ __device__ __forceinline__ void sweep_q16_body(const QArgs& A)
             }
         }
         const float mp = cnt != 0 ? mx : -1.0f;
-        const float lo2 = q16_share_max((mayraise && mp >= 0.0f) ? __fsub_rn(mp, E[cj]) : -1.0f);   // (2)
+        const float lo2 = q16_share_max<>((mayraise && mp >= 0.0f) ? __fsub_rn(mp, E[cj]) : -1.0f);   // (2)
         if (mayraise && lo2 >= 0.0f) {
             const float lb = __fsub_rn(__fmul_rn(lo2, FIC_Q_LEVEL), E[cj]);
             tau[cj] = fmaxf(tau[cj], lb);
@@ -1330,7 +1341,7 @@ __device__ __forceinline__ void sweep_q16_body(const QArgs& A)
                 unit_mfma(a0, cj, x0, x1);
                 const float mx = max8_abs(x0, x1);
                 const bool ok = (okbits >> cj) & 1u, mayraise = (raise >> cj) & 1u;
-                const float lo = __fsub_rn(q16_share_max(ok ? mx : 0.0f), E[cj]);
+                const float lo = __fsub_rn(q16_share_max<true>(ok ? mx : 0.0f), E[cj]);
                 if (mayraise && lo > 0.0f) tau[cj] = fmaxf(tau[cj], __fsub_rn(__fmul_rn(lo, FIC_Q_LEVEL), E[cj]));
             }
         }
