@@ -85,6 +85,7 @@ int ctx_free_all(fic_ctx* c)
                     c->o.a, c->o.b, c->o.err, c->o.qrows, c->o.records};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
+    if (c->host_rec) { (void)hipHostFree(c->host_rec); c->host_rec = nullptr; }
     return FIC_OK;
 }
 
@@ -707,11 +708,29 @@ int fic_ctx_get_results_host(fic_ctx* c, int32_t* idx_local, float* a, float* b,
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->last_stream));
     size_t n = (size_t)c->g.planes * c->g.Nr;
-    if (idx_local) HIP_TRY(hipMemcpy(idx_local, c->o.idx_local, n * 4, hipMemcpyDeviceToHost));
-    if (a) HIP_TRY(hipMemcpy(a, c->o.a, n * 4, hipMemcpyDeviceToHost));
-    if (b) HIP_TRY(hipMemcpy(b, c->o.b, n * 4, hipMemcpyDeviceToHost));
-    if (iso) HIP_TRY(hipMemcpy(iso, c->o.iso, n * 4, hipMemcpyDeviceToHost));
-    if (qrows) HIP_TRY(hipMemcpy(qrows, c->o.qrows, n * 12, hipMemcpyDeviceToHost));
+    // idx_local / a / b / iso / qrows are the six words of the packed 24-byte record (finalize_store): ONE copy into a pinned
+    // buffer of the context and an unpack on the host instead of up to five blocking copies of ~15 us each -- the one-shot entry
+    // the JNI host calls (fic_encode_gray_*) is three of them shorter per call.
+    // (up to 65 536 range blocks: beyond that the copies' latency no longer matters and the host loop would)
+    if (n > (size_t)65536) {
+        if (idx_local) HIP_TRY(hipMemcpy(idx_local, c->o.idx_local, n * 4, hipMemcpyDeviceToHost));
+        if (a) HIP_TRY(hipMemcpy(a, c->o.a, n * 4, hipMemcpyDeviceToHost));
+        if (b) HIP_TRY(hipMemcpy(b, c->o.b, n * 4, hipMemcpyDeviceToHost));
+        if (iso) HIP_TRY(hipMemcpy(iso, c->o.iso, n * 4, hipMemcpyDeviceToHost));
+        if (qrows) HIP_TRY(hipMemcpy(qrows, c->o.qrows, n * 12, hipMemcpyDeviceToHost));
+    } else if (idx_local || a || b || iso || qrows) {
+        std::lock_guard<std::mutex> lk(c->mu);
+        if (!c->host_rec) HIP_TRY(hipHostMalloc((void**)&c->host_rec, n * 6 * sizeof(int32_t), hipHostMallocDefault));
+        HIP_TRY(hipMemcpy(c->host_rec, c->o.records, n * 6 * sizeof(int32_t), hipMemcpyDeviceToHost));
+        const int32_t* r = c->host_rec;
+        for (size_t i = 0; i < n; i++, r += 6) {
+            if (idx_local) idx_local[i] = r[0];
+            if (a) memcpy(&a[i], &r[1], 4);
+            if (b) memcpy(&b[i], &r[2], 4);
+            if (iso) iso[i] = r[3];
+            if (qrows) { qrows[3 * i] = r[0]; qrows[3 * i + 1] = r[4]; qrows[3 * i + 2] = r[5]; }
+        }
+    }
     if (idx_global) HIP_TRY(hipMemcpy(idx_global, c->o.idx_global, n * 4, hipMemcpyDeviceToHost));
     if (err) HIP_TRY(hipMemcpy(err, c->o.err, n * 4, hipMemcpyDeviceToHost));
     return FIC_OK;

@@ -67,6 +67,7 @@ struct fic_ctx {
     uint8_t* gray_own = nullptr;     // context-owned input copy
     int32_t* argb_stage = nullptr;   // staging for ARGB uploads
     int32_t* collage = nullptr;
+    int32_t* host_rec = nullptr;     // pinned host copy of the packed records (fic_ctx_get_results_host)
     uint8_t* decoded = nullptr;      // decoder output image(s)
     FicDecodeState* dec_state = nullptr;   // decoder loop state [planes] and per-pixel squared changes [planes][W*H]
     uint32_t* dec_sq = nullptr;
